@@ -1,0 +1,95 @@
+/*
+ * pctrans_hip.h -- C ABI of libpctrans_hip.so, the MI355X (gfx950) drop-in for the native side of
+ * PCTrans' Mask2Former-style decoder hot path.
+ *
+ * Boundary being replaced (paths relative to the reference checkout,
+ * OPS = connectomics/model/maskformer_block/pixel_decoder/ops):
+ *   OPS/src/vision.cpp:18-21            pybind module `MultiScaleDeformableAttention`
+ *   OPS/src/ms_deform_attn.h:25-67      ms_deform_attn_forward / ms_deform_attn_backward dispatch
+ *   OPS/src/cuda/ms_deform_attn_cuda.cu:25-85, 88-158   host wrappers (checks, alloc, chunk loop)
+ *   OPS/src/cuda/ms_deform_im2col_cuda.cuh:242-304      forward kernel, 306-1331 backward kernels
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / ATen types cross this line.
+ *   - every pointer is a DEVICE pointer (HBM) unless its name starts with `host_`.
+ *   - tensors are dense row-major ("contiguous") exactly as the reference requires (cu:33-37):
+ *       value          [batch, spatial_size, num_heads, channels]
+ *       spatial_shapes [num_levels, 2]  int64, (H_l, W_l)
+ *       level_start    [num_levels]     int64, prefix sums of H_l*W_l
+ *       sampling_loc   [batch, num_query, num_heads, num_levels, num_point, 2]  (x, y) normalised to [0,1]
+ *       attn_weight    [batch, num_query, num_heads, num_levels, num_point]
+ *       output         [batch, num_query, num_heads*channels]
+ *   - inputs are borrowed and never written; outputs are caller-allocated and fully overwritten
+ *     (the caller does NOT need to zero them -- the reference's at::zeros, cu:59/126-128, is folded in).
+ *   - work is enqueued on `stream` (a hipStream_t, may be NULL = default stream); no host sync.
+ *   - return value: 0 on success; >0 = a hipError_t from the launch; <0 = one of PCT_ERR_* below.
+ *     Unlike the reference (which only printf()s launch errors, cuh:953-957) errors are returned.
+ *   - `im2col_step` keeps the reference's precondition batch % min(batch, im2col_step) == 0 (cu:55-57);
+ *     the whole batch is still processed by ONE launch (chunking was a CUDA-grid-size workaround and
+ *     does not change results).
+ */
+#ifndef PCTRANS_HIP_H_
+#define PCTRANS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCT_ABI_VERSION 1
+
+/* exported with default visibility; everything else in the library is hidden */
+#define PCT_API __attribute__((visibility("default")))
+
+#define PCT_OK 0
+#define PCT_ERR_BAD_ARG (-1)      /* null pointer, non-positive size, sizes that overflow int32 indexing */
+#define PCT_ERR_IM2COL_STEP (-2)  /* batch % min(batch, im2col_step) != 0 (cu:57) */
+#define PCT_ERR_ALIGNMENT (-3)    /* a pointer is not aligned to its element size */
+#define PCT_ERR_UNSUPPORTED (-4)  /* shape outside what the kernel supports (documented per entry point) */
+
+PCT_API int pct_abi_version(void);
+/* static string for a code returned by any entry point (hipGetErrorString for >0) */
+PCT_API const char *pct_error_string(int code);
+
+/* ---- MSDeformAttn forward: replaces ms_deform_attn_cuda_forward (cu:25-85) ------------------------------- */
+/* fp32 / fp64: the two dtypes the reference dispatches (AT_DISPATCH_FLOATING_TYPES, cu:69). */
+PCT_API int pct_ms_deform_attn_forward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                   const float *sampling_loc, const float *attn_weight, int batch,
+                                   int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                   int num_point, int im2col_step, float *output, void *stream);
+PCT_API int pct_ms_deform_attn_forward_f64(const double *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                   const double *sampling_loc, const double *attn_weight, int batch,
+                                   int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                   int num_point, int im2col_step, double *output, void *stream);
+/* New capability (not in the reference): 16-bit value/output with fp32 locations, weights and accumulation --
+ * the dtypes torch autocast produces at this boundary (Linear -> bf16/f16 value; softmax and the
+ * reference-point add -> fp32).  `value`/`output` are raw IEEE half / bfloat16 bit patterns. */
+PCT_API int pct_ms_deform_attn_forward_f16(const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                   const float *sampling_loc, const float *attn_weight, int batch,
+                                   int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                   int num_point, int im2col_step, void *output, void *stream);
+PCT_API int pct_ms_deform_attn_forward_bf16(const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                    const float *sampling_loc, const float *attn_weight, int batch,
+                                    int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                    int num_point, int im2col_step, void *output, void *stream);
+
+/* ---- MSDeformAttn backward: replaces ms_deform_attn_cuda_backward (cu:88-158) ----------------------------- */
+/* grad_value [as value], grad_sampling_loc [as sampling_loc], grad_attn_weight [as attn_weight]; all three are
+ * fully defined on return (grad_value is zero-filled on `stream` by the library before the scatter-add). */
+PCT_API int pct_ms_deform_attn_backward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                    const float *sampling_loc, const float *attn_weight, const float *grad_output,
+                                    int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                    int num_query, int num_point, int im2col_step, float *grad_value,
+                                    float *grad_sampling_loc, float *grad_attn_weight, void *stream);
+PCT_API int pct_ms_deform_attn_backward_f64(const double *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                    const double *sampling_loc, const double *attn_weight,
+                                    const double *grad_output, int batch, int spatial_size, int num_heads,
+                                    int channels, int num_levels, int num_query, int num_point, int im2col_step,
+                                    double *grad_value, double *grad_sampling_loc, double *grad_attn_weight,
+                                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCTRANS_HIP_H_ */

@@ -1,0 +1,119 @@
+"""Drop-in for the reference's compiled extension module `MultiScaleDeformableAttention`.
+
+Replaces (reference checkout, OPS = connectomics/model/maskformer_block/pixel_decoder/ops):
+    OPS/src/vision.cpp:18-21                 the pybind module and its two functions
+    OPS/src/ms_deform_attn.h:25-67           device dispatch ("Not implemented on the CPU")
+    OPS/src/cuda/ms_deform_attn_cuda.cu:25-158   contiguity / device asserts, output allocation
+
+Same positional signatures, same error behaviour: non-contiguous or non-device tensors raise, CPU tensors raise
+"Not implemented on the CPU" (callers such as OPS/modules/ms_deform_attn.py:116-121 rely on that exception),
+`batch % min(batch, im2col_step) != 0` raises.  The work itself is one launch of the hand-written gfx950 kernel
+through the C ABI of libpctrans_hip.so on the caller's current stream; nothing is synchronised.
+
+To let reference code `import MultiScaleDeformableAttention` resolve to this module, see `install_as_extension()`.
+"""
+import sys
+
+import torch
+
+from . import _lib
+
+_FWD = {
+    torch.float32: "pct_ms_deform_attn_forward_f32",
+    torch.float64: "pct_ms_deform_attn_forward_f64",
+    torch.float16: "pct_ms_deform_attn_forward_f16",
+    torch.bfloat16: "pct_ms_deform_attn_forward_bf16",
+}
+_BWD = {
+    torch.float32: "pct_ms_deform_attn_backward_f32",
+    torch.float64: "pct_ms_deform_attn_backward_f64",
+}
+
+
+def _check_inputs(named):
+    for name, t in named:
+        if not t.is_contiguous():
+            raise RuntimeError("%s tensor has to be contiguous" % name)          # cu:33-37
+    if not named[0][1].is_cuda:
+        raise RuntimeError("Not implemented on the CPU")                        # ms_deform_attn.h:43
+    dev = named[0][1].device
+    for name, t in named:
+        if not t.is_cuda:
+            raise RuntimeError("%s must be a CUDA tensor" % name)               # cu:39-43 (device tensor on ROCm)
+        if t.device != dev:
+            raise RuntimeError("%s is on %s, value is on %s" % (name, t.device, dev))
+
+
+def _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5 or spatial_shapes.dim() != 2:
+        raise RuntimeError("ms_deform_attn: expected value[N,S,M,D], sampling_loc[N,Lq,M,L,P,2], "
+                           "attn_weight[N,Lq,M,L,P], spatial_shapes[L,2]")
+    N, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Lq, P = sampling_loc.shape[1], sampling_loc.shape[4]
+    if tuple(sampling_loc.shape) != (N, Lq, M, L, P, 2) or tuple(attn_weight.shape) != (N, Lq, M, L, P) \
+            or tuple(spatial_shapes.shape) != (L, 2) or level_start_index.numel() != L:
+        raise RuntimeError("ms_deform_attn: inconsistent shapes value=%s loc=%s attn=%s shapes=%s starts=%s" % (
+            tuple(value.shape), tuple(sampling_loc.shape), tuple(attn_weight.shape),
+            tuple(spatial_shapes.shape), tuple(level_start_index.shape)))
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes and level_start_index must be int64")   # kernels read int64_t (cuh:245-246)
+    return N, S, M, D, L, Lq, P
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    """-> Tensor[N, Lq, M*D].  fp32/fp64 as the reference; fp16/bf16 value with fp32 loc/weights is new capability
+    (loc / weights given in the 16-bit dtype are promoted to fp32 first)."""
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                   ("sampling_loc", sampling_loc), ("attn_weight", attn_weight)])
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    if value.dtype not in _FWD:
+        raise RuntimeError("ms_deform_attn_forward: unsupported dtype %s" % value.dtype)
+    aux = value.dtype if value.dtype in (torch.float32, torch.float64) else torch.float32
+    if sampling_loc.dtype != aux:
+        sampling_loc = sampling_loc.to(aux)
+    if attn_weight.dtype != aux:
+        attn_weight = attn_weight.to(aux)
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        rc = getattr(_lib.lib(), _FWD[value.dtype])(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+            attn_weight.data_ptr(), N, S, M, D, L, Lq, P, int(im2col_step), out.data_ptr(), _stream(value))
+    _lib.check(rc, "ms_deform_attn_forward")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                            im2col_step):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight] (fp32 / fp64, as the reference dispatches)."""
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                   ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)])
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    if value.dtype not in _BWD:
+        raise RuntimeError("ms_deform_attn_backward: unsupported dtype %s" % value.dtype)
+    for name, t in (("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)):
+        if t.dtype != value.dtype:
+            raise RuntimeError("%s dtype %s does not match value dtype %s" % (name, t.dtype, value.dtype))
+    if grad_output.numel() != N * Lq * M * D:
+        raise RuntimeError("grad_output has %d elements, expected %d" % (grad_output.numel(), N * Lq * M * D))
+    grad_value = torch.empty_like(value)
+    grad_loc = torch.empty_like(sampling_loc)
+    grad_attn = torch.empty_like(attn_weight)
+    with torch.cuda.device(value.device):
+        rc = getattr(_lib.lib(), _BWD[value.dtype])(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+            attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L, Lq, P, int(im2col_step),
+            grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), _stream(value))
+    _lib.check(rc, "ms_deform_attn_backward")
+    return [grad_value, grad_loc, grad_attn]
+
+
+def install_as_extension():
+    """Register this module under the top-level name the reference imports
+    (`import MultiScaleDeformableAttention as MSDA`, OPS/functions/ms_deform_attn_func.py:21-22)."""
+    sys.modules["MultiScaleDeformableAttention"] = sys.modules[__name__]
+    return sys.modules[__name__]

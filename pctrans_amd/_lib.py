@@ -1,0 +1,59 @@
+"""ctypes binding of libpctrans_hip.so (C ABI: include/pctrans_hip.h).  Fails loudly if the library is missing."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpctrans_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+
+_vp, _i = ctypes.c_void_p, ctypes.c_int
+_FWD_ARGS = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]
+_BWD_ARGS = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]
+
+SYMBOLS = {
+    "pct_abi_version": ([], _i),
+    "pct_error_string": ([_i], ctypes.c_char_p),
+    "pct_ms_deform_attn_forward_f32": (_FWD_ARGS, _i),
+    "pct_ms_deform_attn_forward_f64": (_FWD_ARGS, _i),
+    "pct_ms_deform_attn_forward_f16": (_FWD_ARGS, _i),
+    "pct_ms_deform_attn_forward_bf16": (_FWD_ARGS, _i),
+    "pct_ms_deform_attn_backward_f32": (_BWD_ARGS, _i),
+    "pct_ms_deform_attn_backward_f64": (_BWD_ARGS, _i),
+}
+
+
+class PctransLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the HIP library.  No fallback: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PctransLibraryError(
+            "libpctrans_hip.so not found at %s -- build it with `make -C pctrans_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`).  "
+            "pctrans_amd has no CPU / eager fallback for device tensors." % LIB_PATH)
+    l = ctypes.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in SYMBOLS.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError as e:
+            raise PctransLibraryError("libpctrans_hip.so does not export %s (stale build?)" % name) from e
+        fn.argtypes = argtypes
+        fn.restype = restype
+    v = l.pct_abi_version()
+    if v != ABI_VERSION:
+        raise PctransLibraryError("libpctrans_hip.so ABI version %d, expected %d -- rebuild" % (v, ABI_VERSION))
+    _lib = l
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().pct_error_string(code).decode()
+        raise RuntimeError("%s failed: %s (code %d)" % (what, msg, code))

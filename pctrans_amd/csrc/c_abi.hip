@@ -1,0 +1,153 @@
+// extern "C" surface of libpctrans_hip.so -- see include/pctrans_hip.h for the contract and the reference
+// interfaces (file:line) each entry point replaces.  Argument validation mirrors the reference host wrappers
+// (ops/src/cuda/ms_deform_attn_cuda.cu:33-57, 98-122); device/contiguity checks need tensor metadata and live in
+// the Python shim (pctrans_amd/MultiScaleDeformableAttention.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pctrans_hip.h"
+#include "msda_common.hpp"
+
+namespace pct {
+template <typename T>
+int launch_msda_forward(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
+                        int, int, int, int, void *, hipStream_t);
+template <typename A>
+int launch_msda_backward(const void *, const int64_t *, const int64_t *, const void *, const void *, const void *,
+                         int, int, int, int, int, int, int, void *, void *, void *, hipStream_t);
+}  // namespace pct
+
+namespace {
+
+int check_common(const void *value, const int64_t *shapes, const int64_t *starts, const void *loc,
+                 const void *attn, int N, int S, int M, int D, int L, int Lq, int P, int im2col_step,
+                 size_t elem, size_t loc_elem)
+{
+  if (N < 0 || S < 0 || Lq < 0 || M <= 0 || D <= 0 || L <= 0 || P <= 0 || im2col_step <= 0) return PCT_ERR_BAD_ARG;
+  if (N == 0) return PCT_OK;
+  const int step = N < im2col_step ? N : im2col_step;
+  if (N % step != 0) return PCT_ERR_IM2COL_STEP;  // cu:57
+  if (!value || !shapes || !starts || !loc || !attn) return PCT_ERR_BAD_ARG;
+  // per-image offsets are 32-bit in the kernels (as in the reference, cuh:260-283)
+  if ((long long)S * M * D >= 0x7fffffffLL) return PCT_ERR_UNSUPPORTED;
+  if ((uintptr_t)value % elem || (uintptr_t)loc % loc_elem || (uintptr_t)attn % loc_elem ||
+      (uintptr_t)shapes % 8 || (uintptr_t)starts % 8)
+    return PCT_ERR_ALIGNMENT;
+  return PCT_OK;
+}
+
+template <typename T, typename LT>
+int forward_impl(const void *value, const int64_t *shapes, const int64_t *starts, const LT *loc, const LT *attn,
+                 int N, int S, int M, int D, int L, int Lq, int P, int im2col_step, void *out, void *stream)
+{
+  const int rc = check_common(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, im2col_step,
+                              sizeof(typename pct::Traits<T>::store_t), sizeof(LT));
+  if (rc != PCT_OK) return rc;
+  if (N == 0 || Lq == 0) return PCT_OK;
+  if (!out) return PCT_ERR_BAD_ARG;
+  if ((uintptr_t)out % sizeof(typename pct::Traits<T>::store_t)) return PCT_ERR_ALIGNMENT;
+  return pct::launch_msda_forward<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out,
+                                     static_cast<hipStream_t>(stream));
+}
+
+template <typename A>
+int backward_impl(const A *value, const int64_t *shapes, const int64_t *starts, const A *loc, const A *attn,
+                  const A *grad_out, int N, int S, int M, int D, int L, int Lq, int P, int im2col_step,
+                  A *grad_value, A *grad_loc, A *grad_attn, void *stream)
+{
+  const int rc = check_common(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, im2col_step, sizeof(A),
+                              sizeof(A));
+  if (rc != PCT_OK) return rc;
+  if (N == 0) return PCT_OK;
+  if (!grad_value || !grad_loc || !grad_attn || (Lq > 0 && !grad_out)) return PCT_ERR_BAD_ARG;
+  if ((uintptr_t)grad_out % sizeof(A) || (uintptr_t)grad_value % sizeof(A) || (uintptr_t)grad_loc % sizeof(A) ||
+      (uintptr_t)grad_attn % sizeof(A))
+    return PCT_ERR_ALIGNMENT;
+  return pct::launch_msda_backward<A>(value, shapes, starts, loc, attn, grad_out, N, S, M, D, L, Lq, P,
+                                      grad_value, grad_loc, grad_attn, static_cast<hipStream_t>(stream));
+}
+
+}  // namespace
+
+extern "C" {
+
+int pct_abi_version(void) { return PCT_ABI_VERSION; }
+
+const char *pct_error_string(int code)
+{
+  switch (code) {
+    case PCT_OK: return "ok";
+    case PCT_ERR_BAD_ARG: return "bad argument (null pointer or non-positive size)";
+    case PCT_ERR_IM2COL_STEP: return "batch must be divisible by min(batch, im2col_step)";
+    case PCT_ERR_ALIGNMENT: return "pointer not aligned to its element size";
+    case PCT_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels";
+    default: break;
+  }
+  if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
+  return "unknown error";
+}
+
+int pct_ms_deform_attn_forward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                   const float *sampling_loc, const float *attn_weight, int batch,
+                                   int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                   int num_point, int im2col_step, float *output, void *stream)
+{
+  return forward_impl<float, float>(value, spatial_shapes, level_start, sampling_loc, attn_weight, batch,
+                                    spatial_size, num_heads, channels, num_levels, num_query, num_point,
+                                    im2col_step, output, stream);
+}
+
+int pct_ms_deform_attn_forward_f64(const double *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                   const double *sampling_loc, const double *attn_weight, int batch,
+                                   int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                   int num_point, int im2col_step, double *output, void *stream)
+{
+  return forward_impl<double, double>(value, spatial_shapes, level_start, sampling_loc, attn_weight, batch,
+                                      spatial_size, num_heads, channels, num_levels, num_query, num_point,
+                                      im2col_step, output, stream);
+}
+
+int pct_ms_deform_attn_forward_f16(const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                   const float *sampling_loc, const float *attn_weight, int batch,
+                                   int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                   int num_point, int im2col_step, void *output, void *stream)
+{
+  return forward_impl<pct::half_bits, float>(value, spatial_shapes, level_start, sampling_loc, attn_weight, batch,
+                                             spatial_size, num_heads, channels, num_levels, num_query, num_point,
+                                             im2col_step, output, stream);
+}
+
+int pct_ms_deform_attn_forward_bf16(const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                    const float *sampling_loc, const float *attn_weight, int batch,
+                                    int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                    int num_point, int im2col_step, void *output, void *stream)
+{
+  return forward_impl<pct::bf16_bits, float>(value, spatial_shapes, level_start, sampling_loc, attn_weight, batch,
+                                             spatial_size, num_heads, channels, num_levels, num_query, num_point,
+                                             im2col_step, output, stream);
+}
+
+int pct_ms_deform_attn_backward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                    const float *sampling_loc, const float *attn_weight, const float *grad_output,
+                                    int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                    int num_query, int num_point, int im2col_step, float *grad_value,
+                                    float *grad_sampling_loc, float *grad_attn_weight, void *stream)
+{
+  return backward_impl<float>(value, spatial_shapes, level_start, sampling_loc, attn_weight, grad_output, batch,
+                              spatial_size, num_heads, channels, num_levels, num_query, num_point, im2col_step,
+                              grad_value, grad_sampling_loc, grad_attn_weight, stream);
+}
+
+int pct_ms_deform_attn_backward_f64(const double *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                    const double *sampling_loc, const double *attn_weight,
+                                    const double *grad_output, int batch, int spatial_size, int num_heads,
+                                    int channels, int num_levels, int num_query, int num_point, int im2col_step,
+                                    double *grad_value, double *grad_sampling_loc, double *grad_attn_weight,
+                                    void *stream)
+{
+  return backward_impl<double>(value, spatial_shapes, level_start, sampling_loc, attn_weight, grad_output, batch,
+                               spatial_size, num_heads, channels, num_levels, num_query, num_point, im2col_step,
+                               grad_value, grad_sampling_loc, grad_attn_weight, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,295 @@
+"""GPU parity tests proper: the HIP kernels, called through the C ABI (ctypes -> libpctrans_hip.so), against
+  (1) the committed golden vectors generated from the reference's own PyTorch function,
+  (2) the C oracle on seeded inputs at sizes it finishes in seconds,
+  (3) size-independent properties at BASELINE.json's full sizes.
+
+Tolerance (north_star: "within 1e-4 fp32"): fp32 forward |err| <= 1e-4 absolute on O(1) data (observed ~1e-6);
+fp64 1e-11; fp16 / bf16 value paths are new capability: compared with the fp32 oracle run on the SAME 16-bit-rounded
+value, error bounded by output rounding (2^-11 resp. 2^-8 relative to |out|, + accumulation slack).
+"""
+import numpy as np
+import pytest
+import torch
+
+from msda_cases import make_case, starts_of
+from oracle import msda_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+FWD_GOLDEN = ["fwd_pow2_L3_f32", "fwd_nonpow2_edges_f32", "fwd_L4_P8_D32_f32", "fwd_oddD_f64",
+              "grad_small_f64", "grad_head_geom_f32"]
+GRAD_GOLDEN = ["fwd_oddD_f64", "grad_small_f64", "grad_head_geom_f32"]
+
+
+@pytest.fixture(scope="module")
+def MSDA():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from pctrans_amd import MultiScaleDeformableAttention as m
+    from pctrans_amd import _lib
+    _lib.lib()   # fail loudly here if the HIP library is missing
+    return m
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_fwd(MSDA, c, step=64):
+    return MSDA.ms_deform_attn_forward(dev(c["value"]), dev(c["shapes"]), dev(c["starts"]), dev(c["loc"]),
+                                       dev(c["attn"]), step).cpu().numpy()
+
+
+def run_bwd(MSDA, c, grad_out, step=64):
+    g = MSDA.ms_deform_attn_backward(dev(c["value"]), dev(c["shapes"]), dev(c["starts"]), dev(c["loc"]),
+                                     dev(c["attn"]), dev(grad_out), step)
+    return [t.cpu().numpy() for t in g]
+
+
+def tol(dtype):
+    return 1e-11 if dtype == np.float64 else 1e-4
+
+
+# ---------------------------------------------------------------- golden vectors -------------------------------
+def test_kat_reference_test_py(MSDA, golden):
+    g = golden("kat_test_py")
+    for tag in ("d1", "d2"):
+        c = dict(value=g[tag + "_value"], shapes=g["shapes"], starts=g["starts"], loc=g[tag + "_loc"],
+                 attn=g[tag + "_attn"])
+        out = run_fwd(MSDA, c, step=2)
+        assert out.shape == (1, 2, 4)
+        np.testing.assert_allclose(out, g[tag + "_out_f32"], rtol=0, atol=1e-8)   # values are O(5e-3)
+        c64 = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in c.items()}
+        np.testing.assert_allclose(run_fwd(MSDA, c64, step=2), g[tag + "_out_f64"], rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("name", FWD_GOLDEN)
+def test_forward_golden(MSDA, golden, name):
+    g = golden(name)
+    out = run_fwd(MSDA, g)
+    assert out.dtype == g["out"].dtype and out.shape == g["out"].shape
+    np.testing.assert_allclose(out, g["out"], rtol=0, atol=tol(out.dtype))
+
+
+@pytest.mark.parametrize("name", GRAD_GOLDEN)
+def test_backward_golden(MSDA, golden, name):
+    g = golden(name)
+    gv, gl, ga = run_bwd(MSDA, g, g["grad_out"])
+    t = 1e-10 if gv.dtype == np.float64 else 1e-4
+    np.testing.assert_allclose(gv, g["grad_value"], rtol=0, atol=t)
+    np.testing.assert_allclose(ga, g["grad_attn"], rtol=0, atol=t)
+    np.testing.assert_allclose(gl, g["grad_loc"], rtol=0, atol=t * 30)     # carries a factor W_l / H_l <= 22
+
+
+# ---------------------------------------------------------------- oracle on seeded inputs ----------------------
+CASES = [
+    # (id, kwargs)  -- BASELINE.json configs at sizes the oracle finishes in seconds
+    ("cfg1_256_L3_Q=S", dict(seed=1, N=1, M=8, D=16, Lq=1344, P=4, shapes=[(8, 8), (16, 16), (32, 32)], model_like=True)),
+    ("cfg2_512_L3_uniform", dict(seed=2, N=2, M=8, D=16, Lq=5376, P=4, shapes=[(16, 16), (32, 32), (64, 64)])),
+    ("cfg2_512_L4_model", dict(seed=3, N=1, M=8, D=16, Lq=21760, P=4,
+                               shapes=[(16, 16), (32, 32), (64, 64), (128, 128)], model_like=True)),
+    ("cfg4_bbbc_nonpow2", dict(seed=4, N=2, M=8, D=16, Lq=7481, P=4, shapes=[(17, 22), (33, 44), (65, 87)],
+                               model_like=True, px_sigma=3.0)),
+    ("cfg3_cvppp_val", dict(seed=5, N=1, M=8, D=16, Lq=700, P=4, shapes=[(17, 16), (34, 32), (67, 63)],
+                            lo=-0.1, hi=1.1)),
+    ("cfg5_L5_P8", dict(seed=6, N=1, M=8, D=16, Lq=3000, P=8,
+                        shapes=[(4, 4), (8, 8), (16, 16), (32, 32), (64, 64)], lo=-0.05, hi=1.05)),
+    ("D32_M4", dict(seed=7, N=3, M=4, D=32, Lq=333, P=4, shapes=[(9, 7), (5, 3)])),
+    ("D64_M2_P3", dict(seed=8, N=2, M=2, D=64, Lq=100, P=3, shapes=[(9, 7), (5, 3)])),
+    ("D4_M1_single_level", dict(seed=9, N=1, M=1, D=4, Lq=77, P=1, shapes=[(3, 5)], lo=-0.5, hi=1.5)),
+    ("D5_scalar_path", dict(seed=10, N=2, M=3, D=5, Lq=41, P=2, shapes=[(6, 4), (3, 2)], lo=-0.2, hi=1.2)),
+    ("D1", dict(seed=11, N=1, M=2, D=1, Lq=19, P=2, shapes=[(2, 2), (1, 1)])),
+    ("D12_cv3", dict(seed=12, N=1, M=5, D=12, Lq=64, P=4, shapes=[(7, 9), (4, 5)])),
+    ("ragged_tail_block", dict(seed=13, N=1, M=3, D=16, Lq=23, P=4, shapes=[(5, 5)])),
+]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("cid,kw", CASES, ids=[c[0] for c in CASES])
+def test_forward_vs_oracle(MSDA, cid, kw, dtype):
+    c = make_case(dtype=dtype, **kw)
+    want = orc.forward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"])
+    got = run_fwd(MSDA, c)
+    np.testing.assert_allclose(got, want, rtol=0, atol=tol(dtype))
+
+
+BWD_CASES = [c for c in CASES if c[0] in ("cfg1_256_L3_Q=S", "cfg4_bbbc_nonpow2", "cfg5_L5_P8", "D32_M4",
+                                           "D64_M2_P3", "D4_M1_single_level", "D5_scalar_path", "D1", "D12_cv3",
+                                           "ragged_tail_block", "cfg3_cvppp_val")]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("cid,kw", BWD_CASES, ids=[c[0] for c in BWD_CASES])
+def test_backward_vs_oracle(MSDA, cid, kw, dtype):
+    c = make_case(dtype=dtype, **kw)
+    N, Lq = c["loc"].shape[:2]
+    MD = c["value"].shape[2] * c["value"].shape[3]
+    go = np.random.RandomState(kw["seed"] + 100).standard_normal((N, Lq, MD)).astype(dtype)
+    want = orc.backward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"], go)
+    got = run_bwd(MSDA, c, go)
+    # grad_value is a sum of up to thousands of atomics in arbitrary order: relative-to-scale tolerance
+    for g, w, name in zip(got, want, ("grad_value", "grad_loc", "grad_attn")):
+        scale = max(1.0, float(np.abs(w).max()))
+        t = (1e-10 if dtype == np.float64 else 2e-5) * scale
+        np.testing.assert_allclose(g, w, rtol=0, atol=t, err_msg=name)
+
+
+def test_autograd_function_matches_oracle(MSDA):
+    from pctrans_amd.pixel_decoder.ops.functions import MSDeformAttnFunction
+    c = make_case(seed=21, N=2, M=8, D=16, Lq=50, P=4, shapes=[(6, 7), (3, 4)], dtype=np.float64, lo=-0.1, hi=1.1)
+    v, loc, a = dev(c["value"]).requires_grad_(), dev(c["loc"]).requires_grad_(), dev(c["attn"]).requires_grad_()
+    out = MSDeformAttnFunction.apply(v, dev(c["shapes"]), dev(c["starts"]), loc, a, 2)
+    go = torch.randn_like(out)
+    out.backward(go)
+    want = orc.backward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"], go.cpu().numpy())
+    for g, w in zip((v.grad, loc.grad, a.grad), want):
+        np.testing.assert_allclose(g.cpu().numpy(), w, rtol=0, atol=1e-10)
+
+
+def test_gradcheck_like_reference_test_py(MSDA):
+    """The reference's gradcheck recipe (OPS/test.py:66-89), channel counts hitting each of our lane layouts."""
+    from torch.autograd import gradcheck
+    from pctrans_amd.pixel_decoder.ops.functions import MSDeformAttnFunction
+    N, M, Lq, L, P = 1, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long).cuda()
+    starts = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    torch.manual_seed(3)
+    for channels in (30, 32, 64, 71, 1025):
+        value = (torch.rand(N, S, M, channels).cuda() * 0.01).double().requires_grad_()
+        loc = torch.rand(N, Lq, M, L, P, 2).cuda().double().requires_grad_()
+        w = torch.rand(N, Lq, M, L, P).cuda() + 1e-5
+        w = (w / w.sum(-1, keepdim=True).sum(-2, keepdim=True)).double().requires_grad_()
+        assert gradcheck(MSDeformAttnFunction.apply, (value, shapes, starts, loc, w, 2)), channels
+
+
+# ---------------------------------------------------------------- 16-bit value paths (new capability) ----------
+@pytest.mark.parametrize("tdt,eps", [(torch.float16, 2.0 ** -11), (torch.bfloat16, 2.0 ** -8)])
+def test_forward_16bit_value(MSDA, tdt, eps):
+    c = make_case(seed=31, N=2, M=8, D=16, Lq=5376, P=4, shapes=[(16, 16), (32, 32), (64, 64)], model_like=True)
+    v16 = torch.from_numpy(c["value"]).to(tdt)
+    c_round = dict(c, value=v16.float().numpy())
+    want = orc.forward(c_round["value"], c["shapes"], c["starts"], c["loc"], c["attn"])
+    got = MSDA.ms_deform_attn_forward(v16.cuda(), dev(c["shapes"]), dev(c["starts"]), dev(c["loc"]), dev(c["attn"]),
+                                      64)
+    assert got.dtype == tdt
+    err = np.abs(got.float().cpu().numpy() - want)
+    assert np.all(err <= eps * np.abs(want) + 1e-5), float(err.max())
+
+
+# ---------------------------------------------------------------- edge cases & error behaviour -----------------
+def test_empty_inputs(MSDA):
+    shapes = torch.tensor([[2, 3]], dtype=torch.long).cuda()
+    starts = torch.tensor([0], dtype=torch.long).cuda()
+    v = torch.randn(2, 6, 2, 4).cuda()
+    out = MSDA.ms_deform_attn_forward(v, shapes, starts, torch.zeros(2, 0, 2, 1, 3, 2).cuda(),
+                                      torch.zeros(2, 0, 2, 1, 3).cuda(), 64)
+    assert out.shape == (2, 0, 8)
+    out = MSDA.ms_deform_attn_forward(v[:0].contiguous(), shapes, starts, torch.zeros(0, 5, 2, 1, 3, 2).cuda(),
+                                      torch.zeros(0, 5, 2, 1, 3).cuda(), 64)
+    assert out.shape == (0, 5, 8)
+
+
+def test_error_behaviour(MSDA):
+    c = make_case(seed=41, N=3, M=2, D=4, Lq=5, P=2, shapes=[(2, 2)])
+    args = [dev(c[k]) for k in ("value", "shapes", "starts", "loc", "attn")]
+    MSDA.ms_deform_attn_forward(*args, 3)
+    MSDA.ms_deform_attn_forward(*args, 128)
+    with pytest.raises(RuntimeError, match="im2col_step"):       # cu:57
+        MSDA.ms_deform_attn_forward(*args, 2)
+    with pytest.raises(RuntimeError, match="contiguous"):        # cu:33
+        MSDA.ms_deform_attn_forward(args[0].transpose(2, 3).contiguous().transpose(2, 3), *args[1:], 3)
+    with pytest.raises(RuntimeError, match="CPU"):               # ms_deform_attn.h:43
+        MSDA.ms_deform_attn_forward(args[0].cpu(), *args[1:], 3)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):       # cu:39-43
+        MSDA.ms_deform_attn_forward(args[0], args[1].cpu(), *args[2:], 3)
+
+
+def test_nan_inf_in_unread_texels_do_not_leak(MSDA):
+    """Corners outside the map read 0 in the reference (cuh:59-82): an Inf elsewhere in `value` must not appear."""
+    shapes = np.array([[4, 4]], dtype=np.int64)
+    v = np.zeros((1, 16, 1, 4), dtype=np.float32)
+    v[0, 0] = np.inf            # texel (0,0): also the clamp target of masked-out corner loads
+    v[0, 5] = 1.0               # texel (1,1)
+    loc = np.array([(1.5 / 4, 1.5 / 4), (-0.05, 0.5), (3.9 / 4, 3.9 / 4), (np.nan, 0.5)], dtype=np.float32)
+    loc = loc.reshape(1, 1, 1, 1, 4, 2)
+    a = np.full((1, 1, 1, 1, 4), 0.25, dtype=np.float32)
+    c = dict(value=v, shapes=shapes, starts=starts_of(shapes), loc=loc, attn=a)
+    got = run_fwd(MSDA, c)
+    want = orc.forward(v, shapes, c["starts"], loc, a)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, atol=1e-6)
+
+
+def test_unaligned_views_take_the_scalar_path(MSDA):
+    """A contiguous view whose data_ptr is only 4-byte aligned must still be correct."""
+    c = make_case(seed=51, N=1, M=2, D=8, Lq=33, P=4, shapes=[(5, 6), (3, 3)])
+    want = orc.forward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"])
+    flat = torch.zeros(c["value"].size + 1).cuda()
+    flat[1:] = dev(c["value"]).flatten()
+    v = flat[1:].view(c["value"].shape)
+    assert v.is_contiguous() and v.data_ptr() % 16 != 0
+    got = MSDA.ms_deform_attn_forward(v, dev(c["shapes"]), dev(c["starts"]), dev(c["loc"]), dev(c["attn"]), 64)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=1e-4)
+
+
+# ---------------------------------------------------------------- full-size properties -------------------------
+FULL = dict(N=8, M=8, D=16, P=4, shapes=[(16, 16), (32, 32), (64, 64), (128, 128)])   # north-star shape, Lq = S
+
+
+def test_fullsize_constant_value_gives_constant_output(MSDA):
+    shapes = np.asarray(FULL["shapes"], dtype=np.int64)
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    g = torch.Generator(device="cuda").manual_seed(0)
+    N, M, D, P, L = FULL["N"], FULL["M"], FULL["D"], FULL["P"], len(shapes)
+    v = torch.full((N, S, M, D), 1.75, device="cuda")
+    # strictly interior samples: pixel coordinate in [0, dim-1]
+    lo = torch.tensor([[0.5 / w, 0.5 / h] for h, w in shapes], device="cuda").view(1, 1, 1, L, 1, 2)
+    loc = lo + torch.rand(N, S, M, L, P, 2, device="cuda", generator=g) * (1 - 2 * lo)
+    a = torch.rand(N, S, M, L, P, device="cuda", generator=g) + 1e-3
+    a = a / a.sum((-1, -2), keepdim=True)
+    out = MSDA.ms_deform_attn_forward(v, dev(shapes), dev(starts_of(shapes)), loc, a, 64)
+    assert out.shape == (N, S, M * D)
+    assert float((out - 1.75).abs().max()) < 1e-5
+
+
+def test_fullsize_linearity_and_head_independence(MSDA):
+    shapes = np.asarray(FULL["shapes"], dtype=np.int64)
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    g = torch.Generator(device="cuda").manual_seed(1)
+    N, M, D, P, L = FULL["N"], FULL["M"], FULL["D"], FULL["P"], len(shapes)
+    sh, st = dev(shapes), dev(starts_of(shapes))
+    v1 = torch.randn(N, S, M, D, device="cuda", generator=g)
+    v2 = torch.randn(N, S, M, D, device="cuda", generator=g)
+    loc = torch.rand(N, S, M, L, P, 2, device="cuda", generator=g) * 1.2 - 0.1
+    a = torch.rand(N, S, M, L, P, device="cuda", generator=g)
+    f = lambda v: MSDA.ms_deform_attn_forward(v, sh, st, loc, a, 8)
+    o1, o2, o12 = f(v1), f(v2), f(2 * v1 - 3 * v2)
+    assert float((o12 - (2 * o1 - 3 * o2)).abs().max()) < 2e-4
+    # changing head 3 of value changes only head 3 of the output
+    v3 = v1.clone()
+    v3[:, :, 3] += 1.0
+    d = (f(v3) - o1).view(N, S, M, D).abs().amax((0, 1, 3))
+    assert float(d[3]) > 0 and float(d[[0, 1, 2, 4, 5, 6, 7]].max()) == 0.0
+
+
+def test_fullsize_pixel_centre_locations_are_an_exact_gather(MSDA):
+    shapes = np.asarray(FULL["shapes"], dtype=np.int64)
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    N, M, D = 2, FULL["M"], FULL["D"]
+    L, P = len(shapes), 1
+    g = torch.Generator(device="cuda").manual_seed(2)
+    v = torch.randn(N, S, M, D, device="cuda", generator=g)
+    # every query looks at one random pixel centre on level 3 with weight 1, weight 0 elsewhere
+    h, w = int(shapes[3, 0]), int(shapes[3, 1])
+    px = torch.randint(0, w, (N, S, M), device="cuda", generator=g)
+    py = torch.randint(0, h, (N, S, M), device="cuda", generator=g)
+    loc = torch.full((N, S, M, L, P, 2), 0.5, device="cuda")
+    loc[:, :, :, 3, 0, 0] = (px + 0.5) / w
+    loc[:, :, :, 3, 0, 1] = (py + 0.5) / h
+    a = torch.zeros(N, S, M, L, P, device="cuda")
+    a[:, :, :, 3, 0] = 1.0
+    out = MSDA.ms_deform_attn_forward(v, dev(shapes), dev(starts_of(shapes)), loc, a, 64).view(N, S, M, D)
+    start3 = int(starts_of(shapes)[3])
+    idx = (start3 + py * w + px)                                      # [N, S, M]
+    want = torch.gather(v, 1, idx[..., None].expand(N, S, M, D))
+    assert float((out - want).abs().max()) < 1e-5
