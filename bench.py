@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- MSDeformAttn pixel decoder + PCTrans transformer decoder forward throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank/GPU)
+
+One "step" = one forward of MaskFormerHead (pixel decoder with 6 MSDeformAttn encoder layers + 9-layer position-
+guided masked-attention decoder + per-query dynamic mask head) over one batch of synthetic ResNet-50-shaped feature
+maps of 512x512 images, 100 queries, eval mode, weights random-initialised by the reference's init recipes.
+Images are independent, so ranks shard them with no data-path collective (weak scaling, DDP-style launch); the only
+collectives are the barriers bracketing the timed region.
+
+The JSON line carries, besides the throughput:
+  roofline      the MSDeformAttn forward kernel (the hot kernel north_star names), timed live with HIP events on its
+                launch stream inside the timed steps; achieved = algorithmic bytes per launch / mean launch time,
+                algorithmic bytes = N * S * (2*M*D*e + 3*M*L*P*4)  (SURVEY.md 8d), peak = 8 TB/s HBM3E.
+  cpu_baseline  the C/OpenMP oracle (oracle/msda_oracle.c, kind "port") timed on this host for the same MSDeformAttn
+                layer shape, rank 0 / N=1 only, bounded to ~10 s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--image", type=int, default=512)
+    ap.add_argument("--queries", type=int, default=100)
+    ap.add_argument("--levels", type=int, default=4, choices=[3, 4],
+                    help="encoder feature levels: 4 = res2..res5 (north-star shape), 3 = res3..res5 (shipped yaml)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
+                    help="autocast dtype of the transformer decoder; the pixel decoder is fp32 as in the reference")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def build_head(args, device):
+    from pctrans_amd.config import get_cfg, resnet_output_shape
+    from pctrans_amd.meta_arch.mask_former_head import MaskFormerHead
+    feats = ("res2", "res3", "res4", "res5") if args.levels == 4 else ("res3", "res4", "res5")
+    cfg = get_cfg(num_queries=args.queries, enc_in_features=feats)
+    shapes = resnet_output_shape(50)
+    torch.manual_seed(0)
+    head = MaskFormerHead(**MaskFormerHead.from_config(cfg, shapes)).to(device).eval()
+    return head, shapes
+
+
+def synth_features(shapes, batch, image, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    return {k: torch.randn(batch, s.channels, image // s.stride, image // s.stride, device=device, generator=g)
+            for k, s in shapes.items()}
+
+
+def cpu_baseline(args, levels_hw):
+    """Oracle MSDeformAttn forward (one encoder layer, one image) on the host cores, bounded in time."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from msda_cases import make_case
+    from oracle import msda_oracle as orc
+    S = sum(h * w for h, w in levels_hw)
+    c = make_case(seed=0, N=1, M=8, D=16, Lq=S, P=4, shapes=levels_hw, model_like=True)
+    threads = orc.max_threads()
+    orc.forward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"])      # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        orc.forward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"])
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= args.cpu_seconds or reps >= 200:
+            break
+    alg_bytes = S * (2 * 128 * 4 + 3 * 8 * len(levels_hw) * 4 * 4)
+    return {"value": reps / el, "unit": "MSDeformAttn-forward image-layers/s", "cores": threads, "kind": "port",
+            "sample": "oracle/msda_oracle.c (C + OpenMP, %d threads) forward, 1 image x %d reps, levels %s, S=%d, "
+                      "M=8 D=16 P=4 fp32, model-like locations" % (threads, reps, list(levels_hw), S),
+            "ms_per_image_layer": 1e3 * el / reps, "algorithmic_GBps": alg_bytes * reps / el / 1e9}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    if world > 1:
+        assert world == args.gpus, "--gpus must equal WORLD_SIZE"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", init_method="env://", device_id=device)   # nccl == RCCL on ROCm
+
+    from pctrans_amd import MultiScaleDeformableAttention as MSDA
+    from pctrans_amd import _lib
+    _lib.lib()      # fail loudly if the HIP library is missing
+
+    head, shapes = build_head(args, device)
+    feats = synth_features(shapes, args.batch, args.image, device, seed=1234 + rank)
+    amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=(args.dtype == "bf16"))
+
+    def step():
+        with torch.no_grad(), amp:
+            pred, _ = head(feats)
+        return pred
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    MSDA.kernel_timing(True)           # HIP events around every MSDeformAttn launch, on the launch stream
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pred = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    launches = MSDA.kernel_timing(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    assert torch.isfinite(pred["pred_masks"].float()).all(), "non-finite output"
+
+    if rank == 0:
+        enc_feats = ["res2", "res3", "res4", "res5"][4 - args.levels:]
+        levels_hw = [(args.image // shapes[k].stride,) * 2 for k in reversed(enc_feats)]     # coarse -> fine
+        S = sum(h * w for h, w in levels_hw)
+        L, M, D, P = len(levels_hw), 8, 16, 4
+        alg_bytes = args.batch * S * (2 * M * D * 4 + 3 * M * L * P * 4)
+        fwd = [ms for name, ms in launches if name == "forward"]
+        mean_ms = sum(fwd) / max(1, len(fwd))
+        achieved = alg_bytes / (mean_ms * 1e-3) / 1e9 if fwd else None
+        out = {
+            "metric": "MSDeformAttn+decoder fwd samples/sec at 512x512, 100 queries",
+            "value": world * args.batch * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16 decoder (autocast) / f32 MSDeformAttn pixel decoder" if args.dtype == "bf16" else "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: %dx%d synthetic, ResNet-50 feature shapes (backbone not in the timed path), "
+                            "MSDeformAttn pixel decoder over %d levels %s + 9-layer masked-attention decoder, "
+                            "%d queries, eval" % (args.image, args.image, L, levels_hw, args.queries),
+                "per_gpu_batch": args.batch, "global_batch": world * args.batch, "levels": L,
+                "queries": args.queries, "parallelism": "dp%d (images sharded, no data-path collective)" % world,
+            },
+            "roofline": {
+                "kernel": "msda_forward_kernel<f32> (MSDeformAttn forward)",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_ms, "launches_timed": len(fwd),
+                "share_of_step": (sum(fwd) / (1e3 * elapsed)) if fwd else None,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, levels_hw)
+            out["cpu_baseline"]["gpu_same_unit"] = args.batch / (mean_ms * 1e-3) if fwd else None
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,6 +65,42 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+# Optional per-launch timing (bench.py's roofline leg): HIP events recorded on the launch stream right before and
+# after the kernel is enqueued.  Off by default; never synchronises while enabled.
+_TIMING = None
+
+
+def kernel_timing(enable):
+    """kernel_timing(True) starts collecting; kernel_timing(False) stops and returns [(name, milliseconds), ...]."""
+    global _TIMING
+    if enable:
+        _TIMING = []
+        return None
+    rec, _TIMING = _TIMING or [], None
+    out = []
+    for name, e0, e1 in rec:
+        e1.synchronize()
+        out.append((name, e0.elapsed_time(e1)))
+    return out
+
+
+class _timed:
+    def __init__(self, name, t):
+        self.name, self.t = name, t
+
+    def __enter__(self):
+        if _TIMING is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(self.t.device))
+
+    def __exit__(self, *exc):
+        if _TIMING is not None and exc[0] is None:
+            self.e1.record(torch.cuda.current_stream(self.t.device))
+            _TIMING.append((self.name, self.e0, self.e1))
+        return False
+
+
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
     """-> Tensor[N, Lq, M*D].  fp32/fp64 as the reference; fp16/bf16 value with fp32 loc/weights is new capability
     (loc / weights given in the 16-bit dtype are promoted to fp32 first)."""
@@ -79,7 +115,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     if attn_weight.dtype != aux:
         attn_weight = attn_weight.to(aux)
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
-    with torch.cuda.device(value.device):
+    with torch.cuda.device(value.device), _timed("forward", value):
         rc = getattr(_lib.lib(), _FWD[value.dtype])(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
             attn_weight.data_ptr(), N, S, M, D, L, Lq, P, int(im2col_step), out.data_ptr(), _stream(value))
@@ -103,7 +139,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_value = torch.empty_like(value)
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
-    with torch.cuda.device(value.device):
+    with torch.cuda.device(value.device), _timed("backward", value):
         rc = getattr(_lib.lib(), _BWD[value.dtype])(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
             attn_weight.data_ptr(), grad_output.data_ptr(), N, S, M, D, L, Lq, P, int(im2col_step),

@@ -27,6 +27,7 @@ int check_common(const void *value, const int64_t *shapes, const int64_t *starts
   if (N == 0) return PCT_OK;
   const int step = N < im2col_step ? N : im2col_step;
   if (N % step != 0) return PCT_ERR_IM2COL_STEP;  // cu:57
+  if (Lq == 0) return PCT_OK;                     // nothing to sample: empty loc / attn may be null
   if (!value || !shapes || !starts || !loc || !attn) return PCT_ERR_BAD_ARG;
   // per-image offsets are 32-bit in the kernels (as in the reference, cuh:260-283)
   if ((long long)S * M * D >= 0x7fffffffLL) return PCT_ERR_UNSUPPORTED;
