@@ -80,13 +80,15 @@ __global__ __launch_bounds__(BWD_BLOCK) void msda_backward_kernel(
 
   auto sample = [&](const int l, const int p, const int H, const int W, const int lvl_off) {
     const int sidx = l * P + p;
-    const A loc_w = rl[2 * sidx], loc_h = rl[2 * sidx + 1], weight = rw[sidx];
+    const A loc_w = rl[2 * sidx], loc_h = rl[2 * sidx + 1], weight_in = rw[sidx];
     const A h_im = loc_h * H - (A)0.5;
     const A w_im = loc_w * W - (A)0.5;
     const bool gate = active && h_im > -1 && w_im > -1 && h_im < H && w_im < W;
     const A hf = floor(h_im), wf = floor(w_im);
     const int h_low = gate ? (int)hf : 0, w_low = gate ? (int)wf : 0;
-    const A lh = h_im - hf, lw = w_im - wf;
+    // gated-out samples get exactly-zero gradients (the reference skips them): neutralise NaN/Inf operands
+    const A lh = gate ? h_im - hf : (A)0, lw = gate ? w_im - wf : (A)0;
+    const A weight = gate ? weight_in : (A)0;
     const A hh = 1 - lh, hw = 1 - lw;
     const bool tp = gate && h_low >= 0, bt = gate && h_low + 1 <= H - 1;
     const bool lf = w_low >= 0, rg = w_low + 1 <= W - 1;

@@ -133,7 +133,10 @@ __global__ __launch_bounds__(FWD_BLOCK) void msda_forward_kernel(
     const bool gate = h_im > -1 && w_im > -1 && h_im < H && w_im < W;   // false for NaN
     const A hf = floor(h_im), wf = floor(w_im);
     const int h_low = gate ? (int)hf : 0, w_low = gate ? (int)wf : 0;   // keep the index math in range
-    const A lh = h_im - hf, lw = w_im - wf;
+    // a gated-out sample must contribute exactly 0 (the reference skips it, cuh:290-296): its fractional parts
+    // and weight may be NaN/Inf (NaN location, Inf*0), so neutralise them instead of relying on 0 * x
+    const A lh = gate ? h_im - hf : (A)0, lw = gate ? w_im - wf : (A)0;
+    const A wgt = gate ? weight : (A)0;
     const A hh = 1 - lh, hw = 1 - lw;
     const bool top = gate && h_low >= 0, bot = gate && h_low + 1 <= H - 1;
     const bool lft = w_low >= 0, rgt = w_low + 1 <= W - 1;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(FWD_BLOCK) void msda_forward_kernel(
     for (int k = 0; k < VEC; ++k) {
       const A a1 = ok1 ? v1[k] : (A)0, a2 = ok2 ? v2[k] : (A)0;
       const A a3 = ok3 ? v3[k] : (A)0, a4 = ok4 ? v4[k] : (A)0;
-      acc[k] += (w1 * a1 + w2 * a2 + w3 * a3 + w4 * a4) * weight;
+      acc[k] += (w1 * a1 + w2 * a2 + w3 * a3 + w4 * a4) * wgt;
     }
   };
 
