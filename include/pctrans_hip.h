@@ -89,6 +89,23 @@ PCT_API int pct_ms_deform_attn_backward_f64(const double *value, const int64_t *
                                     double *grad_value, double *grad_sampling_loc, double *grad_attn_weight,
                                     void *stream);
 
+/* ---- fused per-query dynamic mask head: replaces dynamic_mask_with_coords + mask_heads_forward ---------------
+ * (transformer_decoder/mask2former_transformer_decoder.py:647-719; compute_locations / parse_dynamic_params :929-979)
+ *   mask_feat   [batch, channels, height, width] fp32 (channels must be 16 = MODEL.SEM_SEG_HEAD.MASK_DIM)
+ *   ref_points  [batch, num_query, 2] fp32, normalised (x, y)
+ *   params      [batch, num_query, G] fp32, G = (channels + 2*rel_coord)*8 + 64 + 8 + 8 + 8 + 1, laid out as
+ *               parse_dynamic_params splits the controller output: w0 | w1 | w2 | b0 | b1 | b2
+ *   up_logits   [batch, num_query, 2*height, 2*width]  bilinear x2 (align_corners = False); out_dtype 0 = fp32,
+ *               2 = bfloat16 (logits are then rounded to bf16 before resizing, as the reference's bf16-autocast
+ *               convolutions do)
+ *   attn_mask   [batch, num_query, target_h*target_w] bytes, 1 where sigmoid(resized logit) < 0.5 (= may not attend);
+ *               the reference repeats this per head (:689-691), callers broadcast instead.
+ * Returns PCT_ERR_UNSUPPORTED for channels != 16 (callers then use their dense formulation). */
+PCT_API int pct_dynamic_mask_head_forward(const float *mask_feat, const float *ref_points, const float *params,
+                                          int batch, int channels, int num_query, int height, int width, int stride,
+                                          int rel_coord, int target_h, int target_w, int out_dtype, void *up_logits,
+                                          unsigned char *attn_mask, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,8 @@ int launch_msda_forward(const void *, const int64_t *, const int64_t *, const vo
 template <typename A>
 int launch_msda_backward(const void *, const int64_t *, const int64_t *, const void *, const void *, const void *,
                          int, int, int, int, int, int, int, void *, void *, void *, hipStream_t);
+int launch_dyn_mask_head(const float *, const float *, const float *, int, int, int, int, int, int, int, int, int,
+                         int, void *, unsigned char *, hipStream_t);
 }  // namespace pct
 
 namespace {
@@ -149,6 +151,24 @@ int pct_ms_deform_attn_backward_f64(const double *value, const int64_t *spatial_
   return backward_impl<double>(value, spatial_shapes, level_start, sampling_loc, attn_weight, grad_output, batch,
                                spatial_size, num_heads, channels, num_levels, num_query, num_point, im2col_step,
                                grad_value, grad_sampling_loc, grad_attn_weight, stream);
+}
+
+int pct_dynamic_mask_head_forward(const float *mask_feat, const float *ref_points, const float *params, int batch,
+                                  int channels, int num_query, int height, int width, int stride, int rel_coord,
+                                  int target_h, int target_w, int out_dtype, void *up_logits,
+                                  unsigned char *attn_mask, void *stream)
+{
+  if (batch < 0 || num_query < 0 || channels <= 0 || height <= 0 || width <= 0 || stride <= 0 || target_h <= 0 ||
+      target_w <= 0)
+    return PCT_ERR_BAD_ARG;
+  if (batch == 0 || num_query == 0) return PCT_OK;
+  if (!mask_feat || !params || !up_logits || !attn_mask || (rel_coord && !ref_points)) return PCT_ERR_BAD_ARG;
+  if (((uintptr_t)mask_feat | (uintptr_t)params | (uintptr_t)ref_points) & 3u) return PCT_ERR_ALIGNMENT;
+  if ((uintptr_t)up_logits & 15u) return PCT_ERR_ALIGNMENT;
+  if ((long long)height * width >= 0x7fffffffLL / 64) return PCT_ERR_UNSUPPORTED;
+  return pct::launch_dyn_mask_head(mask_feat, ref_points, params, batch, channels, num_query, height, width, stride,
+                                   rel_coord, target_h, target_w, out_dtype, up_logits, attn_mask,
+                                   static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

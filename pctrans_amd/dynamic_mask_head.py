@@ -1,0 +1,41 @@
+"""Python entry of the fused dynamic mask head kernel (C ABI `pct_dynamic_mask_head_forward`,
+include/pctrans_hip.h; kernel pctrans_amd/csrc/dyn_mask_head.hip).  Forward only: when gradients are needed the
+decoder uses its differentiable batched formulation instead (mask2former_transformer_decoder.py in this package)."""
+import torch
+
+from . import _lib
+
+_OUT = {torch.float32: 0, torch.bfloat16: 2}
+
+
+def supported(mask_feats, rel_coord=True):
+    return mask_feats.is_cuda and mask_feats.dim() == 4 and mask_feats.shape[1] == 16
+
+
+def dynamic_mask_head_forward(mask_feats, ref_xy, params, stride, rel_coord, target_size, out_dtype=torch.float32):
+    """mask_feats [N, 16, H, W]; ref_xy [N, Q, 2] normalised (x, y); params [N, Q, G] in parse_dynamic_params order.
+    -> (logits upsampled x2 [N, Q, 2H, 2W] in `out_dtype`, attention mask bool [N, Q, th*tw], True = may not attend)."""
+    if not mask_feats.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
+    N, C, H, W = mask_feats.shape
+    Q = params.shape[1]
+    G = (C + (2 if rel_coord else 0)) * 8 + 64 + 8 + 8 + 8 + 1
+    if params.shape != (N, Q, G):
+        raise RuntimeError("params must be [N, Q, %d], got %s" % (G, tuple(params.shape)))
+    if out_dtype not in _OUT:
+        raise RuntimeError("out_dtype must be float32 or bfloat16")
+    feats = mask_feats.detach().float().contiguous()
+    prm = params.detach().float().contiguous()
+    ref = ref_xy.detach().float().contiguous() if rel_coord else None
+    if rel_coord and tuple(ref.shape) != (N, Q, 2):
+        raise RuntimeError("ref_xy must be [N, Q, 2]")
+    th, tw = int(target_size[0]), int(target_size[1])
+    up = torch.empty((N, Q, 2 * H, 2 * W), dtype=out_dtype, device=mask_feats.device)
+    amask = torch.empty((N, Q, th * tw), dtype=torch.bool, device=mask_feats.device)
+    with torch.cuda.device(mask_feats.device):
+        rc = _lib.lib().pct_dynamic_mask_head_forward(
+            feats.data_ptr(), ref.data_ptr() if rel_coord else None, prm.data_ptr(), N, C, Q, H, W, int(stride),
+            1 if rel_coord else 0, th, tw, _OUT[out_dtype], up.data_ptr(), amask.data_ptr(),
+            torch.cuda.current_stream(mask_feats.device).cuda_stream)
+    _lib.check(rc, "dynamic_mask_head_forward")
+    return up, amask

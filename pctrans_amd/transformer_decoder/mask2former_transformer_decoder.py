@@ -31,6 +31,7 @@ import torch
 from torch import Tensor, nn
 from torch.nn import functional as F
 
+from .. import dynamic_mask_head as dmh
 from ..layers import Conv2d, c2_xavier_fill, get_norm
 from .attention import MultiheadAttention
 from .position_encoding import PositionEmbeddingSine
@@ -430,6 +431,15 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         N, C, H, W = mask_feats.shape
         Q = reference_points.shape[0]
         params = mask_head_params.transpose(0, 1)                                    # [N, Q, G]
+        needs_grad = torch.is_grad_enabled() and (mask_feats.requires_grad or mask_head_params.requires_grad
+                                                  or reference_points.requires_grad)
+        if mask_feats.is_cuda and not needs_grad and dmh.supported(mask_feats) and self.controller_layers == 3:
+            # fused HIP kernel: MLP + x2 upsample + attention mask in one launch (forward only)
+            out_dtype = torch.bfloat16 if mask_feats.dtype == torch.bfloat16 else torch.float32
+            mask_logits, amask = dmh.dynamic_mask_head_forward(
+                mask_feats, reference_points.transpose(0, 1), params, mask_feat_stride, rel_coord,
+                attn_mask_target_size, out_dtype=out_dtype)
+            return mask_logits, amask.unsqueeze(1)
         mask_logits = self.mask_heads_forward_batched(
             mask_feats, reference_points.transpose(0, 1), params, mask_feat_stride, rel_coord)   # [N, Q, H, W]
 
