@@ -15,6 +15,7 @@ int launch_msda_forward(const void *, const int64_t *, const int64_t *, const vo
 template <typename A>
 int launch_msda_backward(const void *, const int64_t *, const int64_t *, const void *, const void *, const void *,
                          int, int, int, int, int, int, int, void *, void *, void *, hipStream_t);
+void set_win_stamp_buffer(void *);
 int launch_dyn_mask_head(const float *, const float *, const float *, int, int, int, int, int, int, int, int, int,
                          int, void *, unsigned char *, hipStream_t);
 }  // namespace pct
@@ -152,6 +153,9 @@ int pct_ms_deform_attn_backward_f64(const double *value, const int64_t *spatial_
                                spatial_size, num_heads, channels, num_levels, num_query, num_point, im2col_step,
                                grad_value, grad_sampling_loc, grad_attn_weight, stream);
 }
+
+/* diagnostic hook, not part of the product ABI: per-phase cycle stamps of the windowed MSDeformAttn kernel */
+__attribute__((visibility("default"))) void pct_debug_set_stamp_buffer(void *p) { pct::set_win_stamp_buffer(p); }
 
 int pct_dynamic_mask_head_forward(const float *mask_feat, const float *ref_points, const float *params, int batch,
                                   int channels, int num_query, int height, int width, int stride, int rel_coord,

@@ -79,10 +79,14 @@ __global__ __launch_bounds__(DMH_BLOCK) void dyn_mask_head_kernel(
     // The 233 parameters are loop-invariant; hoisted out of the loop they exceed the SGPR file and get spilled to
     // VGPR lanes (one v_readlane per use).  Launder the pointer so they are re-fetched from the scalar cache per
     // iteration, layer by layer, straight into SGPR operands of the FMAs.
-    const float *p = pq;
-    asm volatile("" : "+s"(p));
-    const float *w0 = p, *w1 = p + CIN * DMH_HID, *w2 = w1 + DMH_HID * DMH_HID;
-    const float *b0 = w2 + DMH_HID, *b1 = b0 + DMH_HID, *b2 = b1 + DMH_HID;
+    // The constant address space makes the uniform loads scalar (s_load) even though LDS/global stores precede
+    // them in the loop (the kernel never writes `params`).
+    typedef const __attribute__((address_space(4))) float *cfloat_p;
+    unsigned long long praw = (unsigned long long)pq;
+    asm volatile("" : "+s"(praw));
+    cfloat_p p = (cfloat_p)praw;
+    cfloat_p w0 = p, w1 = p + CIN * DMH_HID, w2 = w1 + DMH_HID * DMH_HID;
+    cfloat_p b0 = w2 + DMH_HID, b1 = b0 + DMH_HID, b2 = b1 + DMH_HID;
     float f[DMH_PX][C];
     float relx[DMH_PX], rely[DMH_PX];
     int idx[DMH_PX];
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(DMH_BLOCK) void dyn_mask_head_kernel(
     float h0[DMH_PX][DMH_HID];
 #pragma unroll
     for (int k = 0; k < DMH_HID; ++k) {
-      const float *wk = w0 + k * CIN;
+      cfloat_p wk = w0 + k * CIN;
       const float bk = b0[k];
 #pragma unroll
       for (int j = 0; j < DMH_PX; ++j) {
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(DMH_BLOCK) void dyn_mask_head_kernel(
     float h1[DMH_PX][DMH_HID];
 #pragma unroll
     for (int k = 0; k < DMH_HID; ++k) {
-      const float *wk = w1 + k * DMH_HID;
+      cfloat_p wk = w1 + k * DMH_HID;
       const float bk = b1[k];
 #pragma unroll
       for (int j = 0; j < DMH_PX; ++j) {
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(DMH_BLOCK) void dyn_mask_head_kernel(
 #pragma unroll
       for (int c = 0; c < DMH_HID; ++c) a = fmaf(w2[c], h1[j][c], a);
       if constexpr (sizeof(OutT) == 2) a = bf16_round(a);       // the reference's conv output is bf16 under autocast
-      if (idx[j] < npx) tile[idx[j]] = a;
+      tile[idx[j] < npx ? idx[j] : npx] = a;                     // tail lanes hit the dummy slot after the tile
     }
   }
   __syncthreads();
@@ -220,14 +224,14 @@ int launch_dyn_mask_head(const float *feat, const float *ref, const float *param
   if ((long long)N * Q == 0 || H == 0 || W == 0) return 0;
   // rows per band: enough blocks to fill the chip several times over, LDS tile <= 48 KB
   int TR = H;
-  const int max_rows = (48 * 1024) / (W * 4) - 2;
+  const int max_rows = (48 * 1024 - 16) / (W * 4) - 2;
   if (max_rows < 1) return -4;
   if (TR > max_rows) TR = max_rows;
   while (TR > 8 && (long long)N * Q * ((H + TR - 1) / TR) < 4096) TR = (TR + 1) / 2;
   const int nbands = (H + TR - 1) / TR;
   const long long nblk = (long long)N * Q * nbands;
   if (nblk > 0x7fffffffLL) return -4;
-  const size_t lds = (size_t)(TR + 2) * W * sizeof(float);
+  const size_t lds = ((size_t)(TR + 2) * W + 4) * sizeof(float);   // + dummy slot for tail lanes
   const dim3 grid((unsigned)nblk), block(DMH_BLOCK);
 #define PCT_DMH(REL_, OUT_)                                                                                   \
   hipLaunchKernelGGL((dyn_mask_head_kernel<16, REL_, OUT_>), grid, block, lds, stream, feat, ref, params, Q, H, \

@@ -15,6 +15,8 @@
 //     branches around loads; an Inf/NaN in an unread texel can not leak through a 0 * v product);
 //   * the point loop is unrolled at compile time for P = 4 / 8 so 4*P 16-byte gathers are in flight per lane;
 //   * logical block order is remapped so that each XCD's L2 serves one contiguous range of queries.
+#include <stdlib.h>
+
 #include "msda_common.hpp"
 
 namespace pct {
@@ -188,6 +190,27 @@ __global__ __launch_bounds__(FWD_BLOCK) void msda_forward_kernel(
   }
 }
 
+// specialised kernels for PCTrans' geometry; each returns -100 when it does not cover the call
+template <typename T>
+int launch_msda_forward_win(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
+                            int, int, int, int, void *, hipStream_t);   // msda_forward_win.hip (LDS windows)
+template <typename T>
+int launch_msda_forward_dpp(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
+                            int, int, int, int, void *, hipStream_t);   // msda_forward_dpp.hip (quad-owner)
+
+// PCT_MSDA_KERNEL = dpp (default) | win | generic : development A/B switch, read once
+static int kernel_choice()
+{
+  static const int v = [] {
+    const char *e = getenv("PCT_MSDA_KERNEL");
+    if (!e) return 0;
+    if (e[0] == 'w') return 1;
+    if (e[0] == 'g') return 2;
+    return 0;
+  }();
+  return v;
+}
+
 // ---- host-side launcher ---------------------------------------------------------------------------------
 template <typename T>
 int launch_msda_forward(const void *value, const int64_t *shapes, const int64_t *starts, const void *loc,
@@ -196,6 +219,15 @@ int launch_msda_forward(const void *value, const int64_t *shapes, const int64_t 
 {
   using A = typename Traits<T>::acc_t;
   using ST = typename Traits<T>::store_t;
+  if constexpr (sizeof(A) == 4) {
+    const int choice = kernel_choice();
+    if (choice != 2) {
+      int rc = -100;
+      if (choice == 1) rc = launch_msda_forward_win<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream);
+      if (rc == -100) rc = launch_msda_forward_dpp<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream);
+      if (rc != -100) return rc;
+    }
+  }
   constexpr int VECW = 16 / (int)sizeof(ST);                    // channels in one 16-byte lane load
   const bool aligned16 = (((uintptr_t)value | (uintptr_t)out) & 15u) == 0 &&
                          (((uintptr_t)loc | (uintptr_t)attn) & 15u) == 0;

@@ -1,0 +1,457 @@
+// MSDeformAttn forward, windowed-LDS gather ("v2") for MI355X (gfx950, wave64).
+//
+// Same semantics as msda_forward.hip (reference: ops/src/cuda/ms_deform_im2col_cuda.cuh:242-304 + :38-89).
+//
+// Why: the straightforward gather moves 4 corners x 64 B per sample = L*P*4*64 B (16-32 KB) per query through the
+// vector-L1 / texture-address path -- ~13x the algorithmic bytes -- and that path, not HBM, bounds the v1 kernel at
+// ~20 % of the HBM roofline.  LDS serves 256 B/clk/CU (ds_read_b128), 4x the L1 path, so:
+//
+//   * work item = (image b, query tile, head m); a tile is TQ = 256/QL queries (QL = lanes per head-pixel, 16 B each):
+//     an 8x8 (QL=4) / 16x8 (QL=2) pixel block of one pyramid level when the queries are the pyramid's own pixels
+//     (Lq == S, PCTrans' encoder self-attention), otherwise TQ consecutive queries.  Which queries share a tile only
+//     affects speed, never results.
+//   * each lane of a query's QL-lane group OWNS points p == lane (mod QL) of every level: it alone loads their
+//     (x, y, weight) (8-B + 4-B loads, no LDS staging, no D-fold redundancy), derives the bilinear geometry once and
+//     later broadcasts it to its siblings with DPP quad_perm moves (register crossbar, no LDS traffic);
+//   * pre-pass: per level the bounding box of every in-map corner the tile touches is reduced with packed-u16
+//     min/max over DPP + readlane + one LDS hop across the 4 waves; boxes are packed into an LDS pool
+//     (64 B per head-pixel) while they fit, the box rows are staged with coalesced 16-B loads, and every sample of a
+//     staged level is then gathered from LDS.  Out-of-map corners point at a zero pixel in LDS (no 0 * Inf hazards).
+//     A level whose box does not fit (coarse-level tiles looking at a fine level, scattered locations) falls back to
+//     the global gather for that level only, still with owner-computed geometry;
+//   * persistent grid: WG g serves XCD (g % 8); each XCD walks one contiguous chunk of the (b, tile, m) items with the
+//     8 heads of a tile adjacent, so the 512-B pixel lines a tile's heads share are fetched into one L2.
+#include <utility>
+
+#include "msda_common.hpp"
+
+namespace pct {
+
+constexpr int WIN_BLOCK = 256;
+constexpr int WIN_TH = 8;              // tile height in pyramid mode (tile width = TQ / 8)
+constexpr int WIN_MAXL = 8;
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b)
+{
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b)
+{
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v)
+{
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v)
+{
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+// quad_perm control that makes every lane of a QL-lane group read lane `src` of its own group
+template <int QL, int SRC>
+struct BcastCtrl {
+  static constexpr int value = QL == 4 ? (SRC | (SRC << 2) | (SRC << 4) | (SRC << 6))
+                                       : (SRC | (SRC << 2) | ((2 + SRC) << 4) | ((2 + SRC) << 6));
+};
+
+// full-wave reduction of packed (u16, u16) values; result in every lane (uniform)
+template <bool IS_MIN>
+__device__ __forceinline__ unsigned wave_reduce_pk(unsigned v)
+{
+  auto op = [](unsigned a, unsigned b) { return IS_MIN ? pk_min(a, b) : pk_max(a, b); };
+  v = op(v, dpp_u<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = op(v, dpp_u<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = op(v, dpp_u<0x141>(v));   // row_half_mirror
+  v = op(v, dpp_u<0x140>(v));   // row_mirror
+  const unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+  const unsigned r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+  return op(op(r0, r1), op(r2, r3));
+}
+
+// One level's window, derived identically by every lane from the 4 per-wave boxes in LDS.
+struct LevelWindow {
+  int x0, y0, wid, size;   // origin, width (pixels), pixel count (0 = no gated sample on this level)
+};
+__device__ __forceinline__ LevelWindow read_window(const unsigned *bb, const int L, const int l)
+{
+  unsigned lo = bb[l * 2], hi = bb[l * 2 + 1];
+#pragma unroll
+  for (int w = 1; w < WIN_BLOCK / 64; ++w) {
+    lo = pk_min(lo, bb[(w * L + l) * 2]);
+    hi = pk_max(hi, bb[(w * L + l) * 2 + 1]);
+  }
+  lo = __builtin_amdgcn_readfirstlane(lo);
+  hi = __builtin_amdgcn_readfirstlane(hi);
+  const int x0 = (int)(lo & 0xFFFFu), y0 = (int)(lo >> 16), x1 = (int)(hi & 0xFFFFu), y1 = (int)(hi >> 16);
+  LevelWindow w;
+  const bool empty = x0 > x1 || y0 > y1;
+  w.x0 = x0;
+  w.y0 = y0;
+  w.wid = empty ? 1 : x1 - x0 + 1;
+  w.size = empty ? 0 : w.wid * (y1 - y0 + 1);
+  return w;
+}
+
+template <typename T, int D, int L, int P, bool STAMP = false>
+__global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
+    const typename Traits<T>::store_t *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn, const int N,
+    const int S, const int M, const int Lq, const int pyramid, const int pool_px,
+    typename Traits<T>::store_t *__restrict__ out, unsigned long long *__restrict__ stamps = nullptr)
+{
+  using ST = typename Traits<T>::store_t;
+  constexpr int VEC = 16 / (int)sizeof(ST);       // channels per lane
+  constexpr int QL = D / VEC;                     // lanes per (query, head) = per head-pixel
+  constexpr int TQ = WIN_BLOCK / QL;              // queries per tile
+  constexpr int TW = TQ / WIN_TH;                 // tile width in pyramid mode
+  constexpr int PPL = P / QL;                     // points each lane owns per level
+  constexpr int PXB = QL * 16;                    // bytes per head-pixel
+  // diagnostic build only (STAMP): per-phase cycle sums of wave 0, written to a buffer nothing else reads
+  unsigned long long t_prev = 0, t_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int phase) {
+    if constexpr (STAMP) {
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (phase >= 0) t_sum[phase] += t - t_prev;
+      t_prev = t;
+    }
+  };
+  static_assert(D % VEC == 0 && (QL == 2 || QL == 4) && P % QL == 0 && L <= WIN_MAXL, "unsupported geometry");
+  using v16 = vec_t<ST, VEC>;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char *pool = smem_raw;                                   // pixel 0 = zeros, then the level windows
+  unsigned *bb = reinterpret_cast<unsigned *>(smem_raw + (size_t)(pool_px + 1) * PXB);   // [4 waves][L][2]
+
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int c = tid & (QL - 1);                   // lane within the query's group
+  const int j = tid / QL;                         // query slot within the tile
+  const int MD = M * D;
+
+  // level geometry (uniform -> SGPRs) and the tile census
+  int Hs[L], Ws[L], St[L], tiles_before[L + 1];
+  tiles_before[0] = 0;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    Hs[l] = (int)shapes[2 * l];
+    Ws[l] = (int)shapes[2 * l + 1];
+    St[l] = (int)starts[l];
+    tiles_before[l + 1] = tiles_before[l] + ((Hs[l] + WIN_TH - 1) / WIN_TH) * ((Ws[l] + TW - 1) / TW);
+  }
+  const int T_img = pyramid ? tiles_before[L] : (Lq + TQ - 1) / TQ;
+  const int items = N * T_img * M;
+
+  if (tid < QL) reinterpret_cast<vec_t<float, 4> *>(pool)[tid] = vec_t<float, 4>{0.f, 0.f, 0.f, 0.f};   // zero pixel
+
+  // persistent, XCD-chunked walk over the items
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int chunk = (items + 7) / 8;
+  const int item_end = min((xcd + 1) * chunk, items);
+
+  // item -> (record index of this lane's query or -1, image, head)
+  auto locate = [&](int item, int &b, int &m) -> long long {
+    m = item % M;
+    const int bt = item / M;
+    const int t = bt % T_img;
+    b = bt / T_img;
+    int q;
+    bool qvalid;
+    if (pyramid) {
+      int Hq = Hs[0], Wq = Ws[0], Sq = St[0], tb = 0;
+#pragma unroll
+      for (int l = 1; l < L; ++l)
+        if (t >= tiles_before[l]) { Hq = Hs[l]; Wq = Ws[l]; Sq = St[l]; tb = tiles_before[l]; }
+      const int tpr = (Wq + TW - 1) / TW;
+      const int tl = t - tb;
+      const int ty = tl / tpr, tx = tl - ty * tpr;
+      const int qy = ty * WIN_TH + j / TW, qx = tx * TW + (j % TW);
+      qvalid = qy < Hq && qx < Wq;
+      q = Sq + qy * Wq + qx;
+    } else {
+      q = t * TQ + j;
+      qvalid = q < Lq;
+    }
+    return qvalid ? ((long long)b * Lq + q) * M + m : -1;
+  };
+  // owner loads: points p = c + k*QL of every level of record `rec` (lanes without a query load record 0)
+  auto load_points = [&](long long rec, float (&x)[L][PPL], float (&y)[L][PPL], float (&w)[L][PPL]) {
+    const long long r = rec < 0 ? 0 : rec;
+    const float *lrec = loc + r * (L * P * 2) + c * 2;
+    const float *wrec = attn + r * (L * P) + c;
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        const vec_t<float, 2> xy = *reinterpret_cast<const vec_t<float, 2> *>(lrec + (l * P + k * QL) * 2);
+        x[l][k] = xy[0];
+        y[l][k] = xy[1];
+        w[l][k] = wrec[l * P + k * QL];
+      }
+  };
+
+  int item = xcd * chunk + slot;
+  float sx[L][PPL], sy[L][PPL], sw[L][PPL];
+  int b = 0, m = 0;
+  long long rec = -1;
+  if (item < item_end) {
+    rec = locate(item, b, m);
+    load_points(rec, sx, sy, sw);
+  }
+
+  for (; item < item_end; item += nslots) {
+    const bool qvalid = rec >= 0;
+    stamp(-1);
+
+    // ---- pre-pass: per-level bounding box of the in-map corners this tile touches ----------------------------
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      unsigned lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        const float h_im = sy[l][k] * Hs[l] - 0.5f, w_im = sx[l][k] * Ws[l] - 0.5f;
+        const bool gate = qvalid && h_im > -1 && w_im > -1 && h_im < Hs[l] && w_im < Ws[l];
+        const int y0 = gate ? (int)floorf(h_im) : 0, x0 = gate ? (int)floorf(w_im) : 0;
+        const unsigned xa = (unsigned)max(x0, 0), xb = (unsigned)min(x0 + 1, Ws[l] - 1);
+        const unsigned ya = (unsigned)max(y0, 0), yb = (unsigned)min(y0 + 1, Hs[l] - 1);
+        lo = gate ? pk_min(lo, xa | (ya << 16)) : lo;
+        hi = gate ? pk_max(hi, xb | (yb << 16)) : hi;
+      }
+      lo = wave_reduce_pk<true>(lo);
+      hi = wave_reduce_pk<false>(hi);
+      if ((tid & 63) == 0) {
+        bb[(wave * L + l) * 2] = lo;
+        bb[(wave * L + l) * 2 + 1] = hi;
+      }
+    }
+    stamp(0);
+    __syncthreads();                                               // (1) boxes visible
+    stamp(1);
+
+    // ---- prefetch the next item's points: in flight underneath staging + gather of this item -----------------
+    float nx[L][PPL], ny[L][PPL], nw[L][PPL];
+    int nb = 0, nm = 0;
+    long long nrec = -1;
+    if (item + nslots < item_end) {
+      nrec = locate(item + nslots, nb, nm);
+      load_points(nrec, nx, ny, nw);
+    }
+
+    // ---- windows (identical in every lane; kept in SGPRs) -------------------------------------------------------
+    int wx0[L], wy0[L], wwid[L], wbase[L], wsize[L], in_lds[L];
+    {
+      int used = 0;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const LevelWindow w = read_window(bb, L, l);
+        wx0[l] = w.x0;
+        wy0[l] = w.y0;
+        wwid[l] = w.wid;
+        wsize[l] = w.size;
+        in_lds[l] = used + w.size <= pool_px ? 1 : 0;
+        wbase[l] = used + 1;                                        // +1: pixel 0 is the zero pixel
+        used += in_lds[l] ? w.size : 0;
+      }
+    }
+
+    stamp(2);
+    // ---- stage the boxes that fit: coalesced 16-B loads, QL lanes per head-pixel ------------------------------
+    const ST *vimg = value + (long long)b * S * MD + m * D;         // this image, this head
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      if (in_lds[l] && wsize[l] > 0) {
+        const float inv_w = 1.0f / (float)wwid[l];
+        const int n16 = wsize[l] * QL;
+        const ST *vlev = vimg + (long long)(St[l] + wy0[l] * Ws[l] + wx0[l]) * MD;
+        unsigned char *dst = pool + (size_t)wbase[l] * PXB;
+#pragma unroll 2
+        for (int i = tid; i < n16; i += WIN_BLOCK) {
+          const int px = i / QL, cc = i & (QL - 1);
+          const int r = (int)(((float)px + 0.5f) * inv_w);
+          const int col = px - r * wwid[l];
+          const v16 v = *reinterpret_cast<const v16 *>(vlev + (long long)(r * Ws[l] + col) * MD + cc * VEC);
+          *reinterpret_cast<v16 *>(dst + (size_t)i * 16) = v;
+        }
+      }
+    }
+    stamp(3);
+    __syncthreads();                                               // (2) windows staged
+    stamp(4);
+
+    // ---- gather ------------------------------------------------------------------------------------------------
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    const ST *vlane = vimg + c * VEC;                               // + lane's channel slice (global path)
+    const unsigned char *pool_lane = pool + c * 16;
+
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int H = Hs[l], W = Ws[l];
+      const bool lds = in_lds[l] != 0;
+      // owner side: geometry of my points on this level (corner offsets + bilinear * attention weights)
+      int o1[PPL], o2[PPL], o3[PPL], o4[PPL];
+      float g1[PPL], g2[PPL], g3[PPL], g4[PPL];
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        const float h_im = sy[l][k] * H - 0.5f, w_im = sx[l][k] * W - 0.5f;
+        const bool gate = qvalid && h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int y0 = gate ? (int)hf : 0, x0 = gate ? (int)wf : 0;
+        const float lh = gate ? h_im - hf : 0.f, lw = gate ? w_im - wf : 0.f;
+        const float wgt = gate ? sw[l][k] : 0.f;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const bool top = gate && y0 >= 0, bot = gate && y0 + 1 <= H - 1;
+        const bool lft = x0 >= 0, rgt = x0 + 1 <= W - 1;
+        const bool ok1 = top && lft, ok2 = top && rgt, ok3 = bot && lft, ok4 = bot && rgt;
+        g1[k] = hh * hw * wgt;
+        g2[k] = hh * lw * wgt;
+        g3[k] = lh * hw * wgt;
+        g4[k] = lh * lw * wgt;
+        // LDS: byte offsets into the pool, out-of-map corners -> the zero pixel (offset 0).
+        // global: element offsets from this image/head base, out-of-map corners -> -1 (load element 0, select 0).
+        const int a = lds ? (wbase[l] + (y0 - wy0[l]) * wwid[l] + (x0 - wx0[l])) * PXB : (St[l] + y0 * W + x0) * MD;
+        const int dx = lds ? PXB : MD, dy = lds ? wwid[l] * PXB : W * MD;
+        const int none = lds ? 0 : -1;
+        o1[k] = ok1 ? a : none;
+        o2[k] = ok2 ? a + dx : none;
+        o3[k] = ok3 ? a + dy : none;
+        o4[k] = ok4 ? a + dy + dx : none;
+      }
+
+      // consumer side: every lane walks all P points, taking point p's geometry from its owner lane by DPP
+      auto consume = [&](auto pc, auto lds_c) {
+        constexpr int p = decltype(pc)::value;
+        constexpr bool LDS = decltype(lds_c)::value;
+        constexpr int k = p / QL;
+        constexpr int ctrl = BcastCtrl<QL, p % QL>::value;
+        const int a1 = dpp_i<ctrl>(o1[k]), a2 = dpp_i<ctrl>(o2[k]);
+        const int a3 = dpp_i<ctrl>(o3[k]), a4 = dpp_i<ctrl>(o4[k]);
+        const float w1 = dpp_f<ctrl>(g1[k]), w2 = dpp_f<ctrl>(g2[k]);
+        const float w3 = dpp_f<ctrl>(g3[k]), w4 = dpp_f<ctrl>(g4[k]);
+        v16 v1, v2, v3, v4;
+        if constexpr (LDS) {
+          v1 = *reinterpret_cast<const v16 *>(pool_lane + (unsigned)a1);
+          v2 = *reinterpret_cast<const v16 *>(pool_lane + (unsigned)a2);
+          v3 = *reinterpret_cast<const v16 *>(pool_lane + (unsigned)a3);
+          v4 = *reinterpret_cast<const v16 *>(pool_lane + (unsigned)a4);
+        } else {
+          v1 = *reinterpret_cast<const v16 *>(vlane + max(a1, 0));
+          v2 = *reinterpret_cast<const v16 *>(vlane + max(a2, 0));
+          v3 = *reinterpret_cast<const v16 *>(vlane + max(a3, 0));
+          v4 = *reinterpret_cast<const v16 *>(vlane + max(a4, 0));
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float x1 = Traits<T>::to_acc(v1[e]), x2 = Traits<T>::to_acc(v2[e]);
+          float x3 = Traits<T>::to_acc(v3[e]), x4 = Traits<T>::to_acc(v4[e]);
+          if constexpr (!LDS) {
+            x1 = a1 < 0 ? 0.f : x1;
+            x2 = a2 < 0 ? 0.f : x2;
+            x3 = a3 < 0 ? 0.f : x3;
+            x4 = a4 < 0 ? 0.f : x4;
+          }
+          acc[e] += w1 * x1 + w2 * x2 + w3 * x3 + w4 * x4;
+        }
+      };
+      if (lds) {
+        [&]<int... Ps>(std::integer_sequence<int, Ps...>) {
+          (consume(std::integral_constant<int, Ps>{}, std::true_type{}), ...);
+        }(std::make_integer_sequence<int, P>{});
+      } else {
+        [&]<int... Ps>(std::integer_sequence<int, Ps...>) {
+          (consume(std::integral_constant<int, Ps>{}, std::false_type{}), ...);
+        }(std::make_integer_sequence<int, P>{});
+      }
+    }
+
+    stamp(5);
+    if (qvalid) {
+      v16 o;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = Traits<T>::from_acc(acc[e]);
+      *reinterpret_cast<v16 *>(out + rec * D + c * VEC) = o;
+    }
+    __syncthreads();                                               // (3) pool / bb free for the next item
+    stamp(6);
+
+    // rotate the prefetched item in
+    rec = nrec;
+    b = nb;
+    m = nm;
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        sx[l][k] = nx[l][k];
+        sy[l][k] = ny[l][k];
+        sw[l][k] = nw[l][k];
+      }
+  }
+  if constexpr (STAMP) {
+    if (tid == 0 && stamps)
+      for (int i = 0; i < 8; ++i) stamps[(size_t)blockIdx.x * 8 + i] = t_sum[i];
+  }
+}
+
+static unsigned long long *g_stamp_buffer = nullptr;
+void set_win_stamp_buffer(void *p) { g_stamp_buffer = static_cast<unsigned long long *>(p); }
+
+// ---- launcher: returns -100 when this geometry is not covered (caller uses the generic kernel) -----------------
+template <typename T>
+int launch_msda_forward_win(const void *value, const int64_t *shapes, const int64_t *starts, const void *loc,
+                            const void *attn, int N, int S, int M, int D, int L, int Lq, int P, void *out,
+                            hipStream_t stream)
+{
+  using ST = typename Traits<T>::store_t;
+  constexpr int VEC = 16 / (int)sizeof(ST);
+  if ((((uintptr_t)value | (uintptr_t)out) & 15u) || (((uintptr_t)loc) & 7u) || (((uintptr_t)attn) & 3u)) return -100;
+  if (D != 16 || !((P == 4 && L >= 3 && L <= 5) || (P == 8 && L == 5))) return -100;
+  if ((long long)N * Lq * M < 32768) return -100;                  // too small to fill a persistent grid
+  if ((long long)N * ((long long)S + 64 * L) * M >= 0x7fffffffLL) return -100;   // item counter is 32-bit
+  constexpr int QL = 16 / VEC;
+  const int pool_px = QL == 4 ? 448 : 896;                          // 28 KB of head-pixels
+  const size_t lds = (size_t)(pool_px + 1) * QL * 16 + (WIN_BLOCK / 64) * WIN_MAXL * 2 * sizeof(unsigned);
+  const int pyramid = Lq == S ? 1 : 0;
+  const dim3 grid(256 * 4), block(WIN_BLOCK);
+  const ST *v = static_cast<const ST *>(value);
+  const float *lc = static_cast<const float *>(loc), *at = static_cast<const float *>(attn);
+  ST *o = static_cast<ST *>(out);
+#define PCT_WIN(L_, P_)                                                                                          \
+  hipLaunchKernelGGL((msda_forward_win_kernel<T, 16, L_, P_>), grid, block, lds, stream, v, shapes, starts, lc, at, \
+                     N, S, M, Lq, pyramid, pool_px, o)
+  if constexpr (sizeof(ST) == 4) {
+    if (g_stamp_buffer && P == 4 && L == 4) {   // diagnostic build: per-phase cycle stamps (tools/stamp_msda.py)
+      hipLaunchKernelGGL((msda_forward_win_kernel<T, 16, 4, 4, true>), grid, block, lds, stream, v, shapes, starts, lc,
+                         at, N, S, M, Lq, pyramid, pool_px, o, g_stamp_buffer);
+      return (int)hipGetLastError();
+    }
+  }
+  if (P == 4 && L == 3) PCT_WIN(3, 4);
+  else if (P == 4 && L == 4) PCT_WIN(4, 4);
+  else if (P == 4 && L == 5) PCT_WIN(5, 4);
+  else if (P == 8 && L == 5) PCT_WIN(5, 8);
+  else return -100;
+#undef PCT_WIN
+  return (int)hipGetLastError();
+}
+
+template int launch_msda_forward_win<float>(const void *, const int64_t *, const int64_t *, const void *,
+                                            const void *, int, int, int, int, int, int, int, void *, hipStream_t);
+template int launch_msda_forward_win<half_bits>(const void *, const int64_t *, const int64_t *, const void *,
+                                                const void *, int, int, int, int, int, int, int, void *,
+                                                hipStream_t);
+template int launch_msda_forward_win<bf16_bits>(const void *, const int64_t *, const int64_t *, const void *,
+                                                const void *, int, int, int, int, int, int, int, void *,
+                                                hipStream_t);
+
+}  // namespace pct

@@ -232,6 +232,58 @@ def test_unaligned_views_take_the_scalar_path(MSDA):
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=1e-4)
 
 
+
+# ---------------------------------------------------------------- windowed-LDS kernel (large problems) ---------
+WIN_CASES = [
+    # big enough (N*Lq*M >= 32768) to take the windowed kernel; pyramid mode (Lq == S) and flat mode (Lq != S)
+    ("win_cfg2_L4_model", dict(seed=61, N=2, M=8, D=16, Lq=21760, P=4,
+                               shapes=[(16, 16), (32, 32), (64, 64), (128, 128)], model_like=True)),
+    ("win_cfg2_L3_uniform_all_fallback", dict(seed=62, N=2, M=8, D=16, Lq=5376, P=4,
+                                              shapes=[(16, 16), (32, 32), (64, 64)])),
+    ("win_bbbc_nonpow2_sigma6", dict(seed=63, N=2, M=8, D=16, Lq=7481, P=4, shapes=[(17, 22), (33, 44), (65, 87)],
+                                     model_like=True, px_sigma=6.0)),
+    ("win_edges_spill", dict(seed=64, N=1, M=8, D=16, Lq=5376, P=4, shapes=[(16, 16), (32, 32), (64, 64)],
+                             lo=-0.3, hi=1.3)),
+    ("win_flat_queries_Lq_ne_S", dict(seed=65, N=3, M=8, D=16, Lq=3000, P=4, shapes=[(20, 30), (10, 15)],
+                                      lo=0.4, hi=0.6)),
+    ("win_L5_P8", dict(seed=66, N=1, M=8, D=16, Lq=5456, P=8,
+                       shapes=[(4, 4), (8, 8), (16, 16), (32, 32), (64, 64)], model_like=True, px_sigma=1.0)),
+    ("win_M4_heads", dict(seed=67, N=4, M=4, D=16, Lq=2320, P=4, shapes=[(40, 50), (16, 20)], model_like=True)),
+]
+
+
+@pytest.mark.parametrize("cid,kw", WIN_CASES, ids=[c[0] for c in WIN_CASES])
+def test_forward_windowed_kernel_vs_oracle(MSDA, cid, kw):
+    c = make_case(dtype=np.float32, **kw)
+    want = orc.forward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"])
+    got = run_fwd(MSDA, c)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)
+
+
+def test_windowed_kernel_tile_local_inf_does_not_leak(MSDA):
+    """A non-finite texel inside a staged window must only reach outputs whose samples really read it."""
+    c = make_case(seed=71, N=1, M=8, D=16, Lq=5376, P=4, shapes=[(16, 16), (32, 32), (64, 64)], model_like=True,
+                  px_sigma=1.0)
+    c["value"][0, 100, 3, :] = np.inf
+    want = orc.forward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"])
+    got = run_fwd(MSDA, c)
+    np.testing.assert_array_equal(np.isfinite(got), np.isfinite(want))
+    fin = np.isfinite(want)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("tdt,eps", [(torch.float16, 2.0 ** -11), (torch.bfloat16, 2.0 ** -8)])
+def test_windowed_kernel_16bit(MSDA, tdt, eps):
+    c = make_case(seed=72, N=2, M=8, D=16, Lq=21760, P=4, shapes=[(16, 16), (32, 32), (64, 64), (128, 128)],
+                  model_like=True)
+    v16 = torch.from_numpy(c["value"]).to(tdt)
+    want = orc.forward(v16.float().numpy(), c["shapes"], c["starts"], c["loc"], c["attn"])
+    got = MSDA.ms_deform_attn_forward(v16.cuda(), dev(c["shapes"]), dev(c["starts"]), dev(c["loc"]), dev(c["attn"]),
+                                      64)
+    err = np.abs(got.float().cpu().numpy() - want)
+    assert np.all(err <= eps * np.abs(want) + 1e-5), float(err.max())
+
+
 # ---------------------------------------------------------------- full-size properties -------------------------
 FULL = dict(N=8, M=8, D=16, P=4, shapes=[(16, 16), (32, 32), (64, 64), (128, 128)])   # north-star shape, Lq = S
 
