@@ -74,6 +74,23 @@ PCT_API int pct_ms_deform_attn_forward_bf16(const void *value, const int64_t *sp
                                     int spatial_size, int num_heads, int channels, int num_levels, int num_query,
                                     int num_point, int im2col_step, void *output, void *stream);
 
+/* ---- MSDeformAttn forward with the module front-end fused in (new entry point, same result) ----------------
+ * Replaces, in one launch, ops/modules/ms_deform_attn.py:100-118 + the op above:
+ *     attention_weights = softmax(attn_logits over num_levels*num_point)
+ *     sampling_locations = ref_points[:, :, None, :, None, :] + offsets / (W_l, H_l)        (2-d reference points)
+ *     output = ms_deform_attn_forward(value, ..., sampling_locations, attention_weights)
+ *   ref_points  [batch or 1, num_query, num_levels, 2] fp32, (x, y) in [0,1]; ref_batch_stride = elements between
+ *               images (0 when one table is shared by the whole batch, as in PCTrans' encoder)
+ *   offsets     [batch, num_query, num_heads, num_levels, num_point, 2] fp32 (output of the sampling_offsets Linear)
+ *   attn_logits [batch, num_query, num_heads, num_levels*num_point]     fp32 (output of the attention_weights Linear)
+ * Supported geometry: channels == 16, num_point in {4, 8}; otherwise PCT_ERR_UNSUPPORTED (callers use the unfused op). */
+PCT_API int pct_ms_deform_attn_fused_forward_f32(const float *value, const int64_t *spatial_shapes,
+                                                 const int64_t *level_start, const float *ref_points,
+                                                 long long ref_batch_stride, const float *offsets,
+                                                 const float *attn_logits, int batch, int spatial_size, int num_heads,
+                                                 int channels, int num_levels, int num_query, int num_point,
+                                                 float *output, void *stream);
+
 /* ---- MSDeformAttn backward: replaces ms_deform_attn_cuda_backward (cu:88-158) ----------------------------- */
 /* grad_value [as value], grad_sampling_loc [as sampling_loc], grad_attn_weight [as attn_weight]; all three are
  * fully defined on return (grad_value is zero-filled on `stream` by the library before the scatter-add). */
@@ -105,6 +122,14 @@ PCT_API int pct_dynamic_mask_head_forward(const float *mask_feat, const float *r
                                           int batch, int channels, int num_query, int height, int width, int stride,
                                           int rel_coord, int target_h, int target_w, int out_dtype, void *up_logits,
                                           unsigned char *attn_mask, void *stream);
+
+/* ---- fused residual add + LayerNorm:  out = LayerNorm(x + y) * gamma + beta  over the last dimension ----------
+ * Replaces the `x + dropout(y)` / `nn.LayerNorm` pairs of the encoder and decoder layers in eval mode
+ * (pixel_decoder/msdeformattn.py:116-131; transformer_decoder/mask2former_transformer_decoder.py:97-99, 179-181,
+ * 216-224).  x, y, out: [rows, cols] fp32 row-major, 16-byte aligned; y may be NULL (plain LayerNorm);
+ * cols in {64, 128, 256}, else PCT_ERR_UNSUPPORTED.  out may alias x or y. */
+PCT_API int pct_add_layernorm_f32(const float *x, const float *y, const float *gamma, const float *beta, float eps,
+                                  long long rows, int cols, float *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -148,6 +148,53 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return [grad_value, grad_loc, grad_attn]
 
 
+def fused_forward_supported(value, reference_points, sampling_offsets):
+    """Geometry the fused front-end kernel covers (PCTrans: fp32, 16 channels per head, 4 or 8 points, 2-d refs)."""
+    return (value.is_cuda and value.dtype == torch.float32 and value.dim() == 4 and value.shape[3] == 16
+            and sampling_offsets.shape[4] in (4, 8) and reference_points.shape[-1] == 2
+            and value.numel() * 4 < 2 ** 31 - 1)
+
+
+def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
+                                 attention_logits):
+    """MSDeformAttn.forward's middle section in one launch (OPS/modules/ms_deform_attn.py:100-118):
+    softmax(attention_logits over L*P), reference_points + sampling_offsets / (W_l, H_l), then the sampling op.
+
+    value [N,S,M,16] fp32; reference_points [N or 1, Lq, L, 2] (an expanded, stride-0 batch dim is accepted);
+    sampling_offsets [N,Lq,M,L,P,2]; attention_logits [N,Lq,M,L*P] (raw Linear outputs) -> [N, Lq, M*16].
+    Forward only (no autograd): the module uses it when no gradient is required."""
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                   ("sampling_offsets", sampling_offsets), ("attention_logits", attention_logits)])
+    N, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Lq, P = sampling_offsets.shape[1], sampling_offsets.shape[4]
+    if tuple(sampling_offsets.shape) != (N, Lq, M, L, P, 2) or attention_logits.numel() != N * Lq * M * L * P:
+        raise RuntimeError("ms_deform_attn_fused_forward: inconsistent shapes")
+    if not fused_forward_supported(value, reference_points, sampling_offsets):
+        raise RuntimeError("ms_deform_attn_fused_forward: unsupported geometry (use the unfused op)")
+    if sampling_offsets.dtype != torch.float32 or attention_logits.dtype != torch.float32:
+        raise RuntimeError("ms_deform_attn_fused_forward: offsets / logits must be float32")
+    ref = reference_points
+    if ref.dtype != torch.float32 or not ref.is_cuda:
+        raise RuntimeError("reference_points must be a float32 device tensor")
+    if tuple(ref.shape[1:]) != (Lq, L, 2) or ref.shape[0] not in (1, N):
+        raise RuntimeError("reference_points must be [N or 1, Lq, L, 2]")
+    if ref.stride()[1:] != (L * 2, 2, 1):
+        ref = ref.contiguous()
+    batch_stride = 0 if (ref.shape[0] == 1 or ref.stride(0) == 0) else ref.stride(0)
+    if batch_stride not in (0, Lq * L * 2):
+        ref = ref.contiguous()
+        batch_stride = Lq * L * 2
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device), _timed("forward", value):
+        rc = _lib.lib().pct_ms_deform_attn_fused_forward_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), ref.data_ptr(), batch_stride,
+            sampling_offsets.data_ptr(), attention_logits.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(),
+            _stream(value))
+    _lib.check(rc, "ms_deform_attn_fused_forward")
+    return out
+
+
 def install_as_extension():
     """Register this module under the top-level name the reference imports
     (`import MultiScaleDeformableAttention as MSDA`, OPS/functions/ms_deform_attn_func.py:21-22)."""

@@ -16,6 +16,11 @@ template <typename A>
 int launch_msda_backward(const void *, const int64_t *, const int64_t *, const void *, const void *, const void *,
                          int, int, int, int, int, int, int, void *, void *, void *, hipStream_t);
 void set_win_stamp_buffer(void *);
+int launch_add_layernorm(const float *, const float *, const float *, const float *, float, long long, int, float *,
+                         hipStream_t);
+template <typename T>
+int launch_msda_forward_dpp(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
+                            int, int, int, int, void *, hipStream_t, const float *, long long);
 int launch_dyn_mask_head(const float *, const float *, const float *, int, int, int, int, int, int, int, int, int,
                          int, void *, unsigned char *, hipStream_t);
 }  // namespace pct
@@ -131,6 +136,25 @@ int pct_ms_deform_attn_forward_bf16(const void *value, const int64_t *spatial_sh
                                              im2col_step, output, stream);
 }
 
+int pct_ms_deform_attn_fused_forward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                                         const float *ref_points, long long ref_batch_stride, const float *offsets,
+                                         const float *attn_logits, int batch, int spatial_size, int num_heads,
+                                         int channels, int num_levels, int num_query, int num_point, float *output,
+                                         void *stream)
+{
+  const int rc = check_common(value, spatial_shapes, level_start, offsets, attn_logits, batch, spatial_size, num_heads,
+                              channels, num_levels, num_query, num_point, 1, sizeof(float), sizeof(float));
+  if (rc != PCT_OK) return rc;
+  if (batch == 0 || num_query == 0) return PCT_OK;
+  if (!output || !ref_points || ref_batch_stride < 0) return PCT_ERR_BAD_ARG;
+  if (((uintptr_t)output | (uintptr_t)ref_points) & 3u) return PCT_ERR_ALIGNMENT;
+  const int r = pct::launch_msda_forward_dpp<float>(value, spatial_shapes, level_start, offsets, attn_logits, batch,
+                                                    spatial_size, num_heads, channels, num_levels, num_query,
+                                                    num_point, output, static_cast<hipStream_t>(stream), ref_points,
+                                                    ref_batch_stride);
+  return r == -100 ? PCT_ERR_UNSUPPORTED : r;
+}
+
 int pct_ms_deform_attn_backward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,
                                     const float *sampling_loc, const float *attn_weight, const float *grad_output,
                                     int batch, int spatial_size, int num_heads, int channels, int num_levels,
@@ -173,6 +197,16 @@ int pct_dynamic_mask_head_forward(const float *mask_feat, const float *ref_point
   return pct::launch_dyn_mask_head(mask_feat, ref_points, params, batch, channels, num_query, height, width, stride,
                                    rel_coord, target_h, target_w, out_dtype, up_logits, attn_mask,
                                    static_cast<hipStream_t>(stream));
+}
+
+int pct_add_layernorm_f32(const float *x, const float *y, const float *gamma, const float *beta, float eps,
+                          long long rows, int cols, float *out, void *stream)
+{
+  if (rows < 0 || cols <= 0) return PCT_ERR_BAD_ARG;
+  if (rows == 0) return PCT_OK;
+  if (!x || !gamma || !beta || !out) return PCT_ERR_BAD_ARG;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15u) return PCT_ERR_ALIGNMENT;
+  return pct::launch_add_layernorm(x, y, gamma, beta, eps, rows, cols, out, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -196,7 +196,7 @@ int launch_msda_forward_win(const void *, const int64_t *, const int64_t *, cons
                             int, int, int, int, void *, hipStream_t);   // msda_forward_win.hip (LDS windows)
 template <typename T>
 int launch_msda_forward_dpp(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
-                            int, int, int, int, void *, hipStream_t);   // msda_forward_dpp.hip (quad-owner)
+                            int, int, int, int, void *, hipStream_t, const float *, long long);   // msda_forward_dpp.hip
 
 // PCT_MSDA_KERNEL = dpp (default) | win | generic : development A/B switch, read once
 static int kernel_choice()
@@ -224,7 +224,8 @@ int launch_msda_forward(const void *value, const int64_t *shapes, const int64_t 
     if (choice != 2) {
       int rc = -100;
       if (choice == 1) rc = launch_msda_forward_win<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream);
-      if (rc == -100) rc = launch_msda_forward_dpp<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream);
+      if (rc == -100)
+        rc = launch_msda_forward_dpp<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream, nullptr, 0);
       if (rc != -100) return rc;
     }
   }

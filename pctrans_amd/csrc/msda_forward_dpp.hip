@@ -15,6 +15,8 @@
 //     and an Inf/NaN in an unread texel can not leak;
 //   * accumulation is a chain of 4 packed FMAs per channel pair straight into the accumulator;
 //   * the next level's points are fetched while the current level is gathered.
+#include <math.h>
+
 #include <utility>
 
 #include "msda_common.hpp"
@@ -46,12 +48,16 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // Consecutive queries are row-adjacent pixels in PCTrans' encoder, so neighbouring lanes share bilinear corners and
 // the wave's working set per level shrinks ~4x -> vector-L1 hit rate up (measured: profiles/r01_*_pmc).
 // !QMAJOR: records in memory order (2 queries x 8 heads per wave); used when M > 16.
-template <typename T, int D, int P, bool QMAJOR>
+// FUSED: the module front-end (ops/modules/ms_deform_attn.py:100-109) is folded in -- `loc` holds the raw
+// sampling offsets, `attn` the raw attention logits, and the kernel forms
+//     weights = softmax over the record's L*P logits,   location = ref[q, l] + offset / (W_l, H_l)
+// itself, so the [N,Lq,M,L,P,2] sampling_locations tensor and the softmax output never exist in HBM.
+template <typename T, int D, int P, bool QMAJOR, bool FUSED>
 __global__ __launch_bounds__(1024) void msda_forward_dpp_kernel(
     const typename Traits<T>::store_t *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn, const int S,
     const int M, const int L, const int Lq, const long long total_recs, const unsigned value_bytes,
-    typename Traits<T>::store_t *__restrict__ out)
+    typename Traits<T>::store_t *__restrict__ out, const float *__restrict__ ref, const long long ref_batch_stride)
 {
   using ST = typename Traits<T>::store_t;
   constexpr int VEC = 16 / (int)sizeof(ST);       // channels per lane
@@ -81,6 +87,28 @@ __global__ __launch_bounds__(1024) void msda_forward_dpp_kernel(
 
   const float *lrec = loc + rec * ((long long)L * P * 2) + c * 2;
   const float *wrec = attn + rec * ((long long)L * P) + c;
+
+  // FUSED: softmax statistics of this record's L*P logits (each lane sees its own points; the QL lanes combine by DPP)
+  float sm_max = 0.f, sm_inv = 1.f;
+  const float *rrec = nullptr;
+  if constexpr (FUSED) {
+    const long long gq = rec / M;                                   // b * Lq + q
+    rrec = ref + b * ref_batch_stride + (gq - b * Lq) * ((long long)L * 2);
+    float mx = -INFINITY;
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) mx = fmaxf(mx, wrec[l * P + k * QL]);
+    mx = fmaxf(mx, qbcast_f<QL == 4 ? 0xB1 : 0xB1>(mx));            // lane ^ 1
+    if constexpr (QL == 4) mx = fmaxf(mx, qbcast_f<0x4E>(mx));      // lane ^ 2
+    float sum = 0.f;
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) sum += expf(wrec[l * P + k * QL] - mx);
+    sum += qbcast_f<0xB1>(sum);
+    if constexpr (QL == 4) sum += qbcast_f<0x4E>(sum);
+    sm_max = mx;
+    sm_inv = 1.f / sum;
+  }
 
   float acc[VEC];
 #pragma unroll
@@ -117,6 +145,16 @@ __global__ __launch_bounds__(1024) void msda_forward_dpp_kernel(
     }
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
     const unsigned lvl = (unsigned)starts[l] * MDb;
+    if constexpr (FUSED) {
+      const float rx = rrec[2 * l], ry = rrec[2 * l + 1];
+      const float fw = (float)W, fh = (float)H;
+#pragma unroll
+      for (int k = 0; k < PPL; ++k) {
+        cx[k] = rx + cx[k] / fw;                                    // reference_points + offsets / (W_l, H_l)
+        cy[k] = ry + cy[k] / fh;
+        cw[k] = expf(cw[k] - sm_max) * sm_inv;                      // softmax weight
+      }
+    }
 
     // owner side: corner byte offsets (relative to lane_base) and bilinear * attention weights of my points
     unsigned o1[PPL], o2[PPL], o3[PPL], o4[PPL];
@@ -179,11 +217,13 @@ __global__ __launch_bounds__(1024) void msda_forward_dpp_kernel(
   }
 }
 
-// returns -100 when this geometry is not covered (caller falls through to the generic kernel)
+// returns -100 when this geometry is not covered (caller falls through to the generic kernel).
+// ref == nullptr: plain op (loc = sampling locations, attn = attention weights);
+// ref != nullptr: fused front-end (loc = raw offsets, attn = raw logits, ref = [N or 1, Lq, L, 2] reference points).
 template <typename T>
 int launch_msda_forward_dpp(const void *value, const int64_t *shapes, const int64_t *starts, const void *loc,
                             const void *attn, int N, int S, int M, int D, int L, int Lq, int P, void *out,
-                            hipStream_t stream)
+                            hipStream_t stream, const float *ref, long long ref_batch_stride)
 {
   using ST = typename Traits<T>::store_t;
   constexpr int VEC = 16 / (int)sizeof(ST);
@@ -202,24 +242,32 @@ int launch_msda_forward_dpp(const void *value, const int64_t *shapes, const int6
   const ST *v = static_cast<const ST *>(value);
   const float *lc = static_cast<const float *>(loc), *at = static_cast<const float *>(attn);
   ST *o = static_cast<ST *>(out);
-#define PCT_DPP(P_, QM_)                                                                                          \
-  hipLaunchKernelGGL((msda_forward_dpp_kernel<T, 16, P_, QM_>), grid, block, 0, stream, v, shapes, starts, lc, at, S, \
-                     M, L, Lq, total_recs, (unsigned)vbytes, o)
-  if (P == 4 && qmajor) PCT_DPP(4, true);
-  else if (P == 4) PCT_DPP(4, false);
-  else if (qmajor) PCT_DPP(8, true);
-  else PCT_DPP(8, false);
+#define PCT_DPP(P_, QM_, FU_)                                                                                      \
+  hipLaunchKernelGGL((msda_forward_dpp_kernel<T, 16, P_, QM_, FU_>), grid, block, 0, stream, v, shapes, starts, lc, \
+                     at, S, M, L, Lq, total_recs, (unsigned)vbytes, o, ref, ref_batch_stride)
+  if (ref) {
+    if (P == 4 && qmajor) PCT_DPP(4, true, true);
+    else if (P == 4) PCT_DPP(4, false, true);
+    else if (qmajor) PCT_DPP(8, true, true);
+    else PCT_DPP(8, false, true);
+  } else {
+    if (P == 4 && qmajor) PCT_DPP(4, true, false);
+    else if (P == 4) PCT_DPP(4, false, false);
+    else if (qmajor) PCT_DPP(8, true, false);
+    else PCT_DPP(8, false, false);
+  }
 #undef PCT_DPP
   return (int)hipGetLastError();
 }
 
 template int launch_msda_forward_dpp<float>(const void *, const int64_t *, const int64_t *, const void *,
-                                            const void *, int, int, int, int, int, int, int, void *, hipStream_t);
+                                            const void *, int, int, int, int, int, int, int, void *, hipStream_t,
+                                            const float *, long long);
 template int launch_msda_forward_dpp<half_bits>(const void *, const int64_t *, const int64_t *, const void *,
-                                                const void *, int, int, int, int, int, int, int, void *,
-                                                hipStream_t);
+                                                const void *, int, int, int, int, int, int, int, void *, hipStream_t,
+                                                const float *, long long);
 template int launch_msda_forward_dpp<bf16_bits>(const void *, const int64_t *, const int64_t *, const void *,
-                                                const void *, int, int, int, int, int, int, int, void *,
-                                                hipStream_t);
+                                                const void *, int, int, int, int, int, int, int, void *, hipStream_t,
+                                                const float *, long long);
 
 }  // namespace pct

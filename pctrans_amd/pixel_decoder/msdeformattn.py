@@ -25,6 +25,7 @@ from torch import nn
 from torch.nn import functional as F
 from torch.nn.init import normal_
 
+from .. import fused_ops
 from ..layers import Conv2d, ShapeSpec, c2_xavier_fill, get_norm
 from ..transformer_decoder.position_encoding import PositionEmbeddingSine
 from .ops.modules import MSDeformAttn
@@ -61,14 +62,25 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
     def with_pos_embed(tensor, pos):
         return tensor if pos is None else tensor + pos
 
+    def _eval_fused(self, src):
+        # forward-only fused kernels: residual+LayerNorm in one pass, bias+ReLU in the GEMM epilogue
+        return (not self.training or self.dropout1.p == 0.0) and src.is_cuda and src.dtype == torch.float32 \
+            and not (torch.is_grad_enabled() and src.requires_grad) and self.activation is F.relu
+
     def forward_ffn(self, src):
+        if self._eval_fused(src):
+            src2 = self.linear2(fused_ops.linear_relu(src, self.linear1))
+            return fused_ops.add_layer_norm(src, src2, self.norm2)
         src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
         return self.norm2(src + self.dropout3(src2))
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         src2 = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
                               level_start_index, padding_mask)
-        src = self.norm1(src + self.dropout1(src2))
+        if self._eval_fused(src):
+            src = fused_ops.add_layer_norm(src, src2, self.norm1)
+        else:
+            src = self.norm1(src + self.dropout1(src2))
         return self.forward_ffn(src)
 
 

@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
+from .... import MultiScaleDeformableAttention as MSDA
 from ..functions import MSDeformAttnFunction, ms_deform_attn_core_pytorch
 
 _ALLOW_CPU_REFERENCE = False
@@ -76,6 +77,13 @@ class MSDeformAttn(nn.Module):
         xavier_uniform_(self.output_proj.weight.data)
         constant_(self.output_proj.bias.data, 0.)
 
+    def _can_fuse(self, value, query, reference_points):
+        if not value.is_cuda or (torch.is_grad_enabled() and (value.requires_grad or query.requires_grad)):
+            return False
+        return (value.dtype == torch.float32 and query.dtype == torch.float32 and reference_points.shape[-1] == 2
+                and self.d_model // self.n_heads == 16 and self.n_points in (4, 8) and self.n_heads <= 16
+                and value.numel() * 4 < 2 ** 31 - 1)
+
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
         """query (N, Lq, C); reference_points (N, Lq, n_levels, 2|4) in [0,1]; input_flatten (N, sum H_l*W_l, C);
@@ -89,6 +97,14 @@ class MSDeformAttn(nn.Module):
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        if self._can_fuse(value, query, reference_points):
+            # one launch: softmax + location math + sampling (no sampling_locations tensor, no softmax output)
+            offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+            logits = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
+            output = MSDA.ms_deform_attn_fused_forward(
+                value.contiguous(), input_spatial_shapes, input_level_start_index, reference_points,
+                offsets.contiguous(), logits.contiguous())
+            return self.output_proj(output)
         sampling_offsets = self.sampling_offsets(query).view(
             N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
         attention_weights = self.attention_weights(query).view(

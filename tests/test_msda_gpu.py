@@ -345,3 +345,53 @@ def test_fullsize_pixel_centre_locations_are_an_exact_gather(MSDA):
     idx = (start3 + py * w + px)                                      # [N, S, M]
     want = torch.gather(v, 1, idx[..., None].expand(N, S, M, D))
     assert float((out - want).abs().max()) < 1e-5
+
+
+# ---------------------------------------------------------------- fused front-end (softmax + locations in-kernel) ---
+@pytest.mark.parametrize("shapes,P,N,shared_ref", [
+    ([(16, 16), (32, 32), (64, 64), (128, 128)], 4, 2, True),
+    ([(17, 22), (33, 44), (65, 87)], 4, 2, False),
+    ([(4, 4), (8, 8), (16, 16), (32, 32), (64, 64)], 8, 1, True),
+    ([(5, 7)], 4, 3, False),
+])
+def test_fused_front_end_equals_module_math(MSDA, shapes, P, N, shared_ref):
+    """fused(value, ref, offsets, logits) == unfused op on (ref + offsets/(W,H), softmax(logits)) -- both through the C ABI,
+    and == the oracle on the same host-computed locations/weights."""
+    rng = np.random.RandomState(5)
+    sh = np.asarray(shapes, dtype=np.int64)
+    L, M, D = len(shapes), 8, 16
+    S = int((sh[:, 0] * sh[:, 1]).sum())
+    Lq = S
+    value = rng.standard_normal((N, S, M, D)).astype(np.float32)
+    offsets = (rng.standard_normal((N, Lq, M, L, P, 2)) * 3).astype(np.float32)
+    logits = (rng.standard_normal((N, Lq, M, L * P)) * 2).astype(np.float32)
+    ref = rng.random_sample((1 if shared_ref else N, Lq, L, 2)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).cuda()
+    ref_t = t(ref).expand(N, -1, -1, -1) if shared_ref else t(ref)
+    got = MSDA.ms_deform_attn_fused_forward(t(value), t(sh), t(starts_of(sh)), ref_t, t(offsets), t(logits))
+    # the module's own math on the device (OPS/modules/ms_deform_attn.py:102-109)
+    norm = torch.stack([t(sh)[:, 1], t(sh)[:, 0]], -1)
+    loc = ref_t[:, :, None, :, None, :] + t(offsets) / norm[None, None, None, :, None, :]
+    w = torch.softmax(t(logits), -1).view(N, Lq, M, L, P)
+    unfused = MSDA.ms_deform_attn_forward(t(value), t(sh), t(starts_of(sh)), loc.contiguous(), w.contiguous(), 64)
+    assert float((got - unfused).abs().max()) <= 1e-4
+    want = orc.forward(value, sh, starts_of(sh), loc.cpu().numpy(), w.cpu().numpy())
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=1e-4)
+
+
+def test_module_fused_path_matches_reference_module_golden(MSDA, golden):
+    """MSDeformAttn module on the GPU (fused front-end kernel, no grad) against the golden vector produced by the
+    reference's own module (tests/golden/module_L3_d128.npz)."""
+    from pctrans_amd.pixel_decoder.ops.modules import MSDeformAttn
+    g = golden("module_L3_d128")
+    m = MSDeformAttn(d_model=128, n_levels=3, n_heads=8, n_points=4)
+    m.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}, strict=True)
+    m = m.cuda().eval()
+    args = [torch.from_numpy(g[k]).cuda() for k in ("query", "ref", "src", "shapes", "starts")]
+    with torch.no_grad():
+        out = m(*args)                                   # fused kernel
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=0, atol=1e-4)
+    out2 = m(*args)                                      # grad enabled -> unfused op + autograd function
+    np.testing.assert_allclose(out2.detach().cpu().numpy(), g["out"], rtol=0, atol=1e-4)
+    out2.sum().backward()
+    assert m.value_proj.weight.grad is not None and torch.isfinite(m.sampling_offsets.weight.grad).all()
