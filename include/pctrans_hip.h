@@ -131,6 +131,19 @@ PCT_API int pct_dynamic_mask_head_forward(const float *mask_feat, const float *r
 PCT_API int pct_add_layernorm_f32(const float *x, const float *y, const float *gamma, const float *beta, float eps,
                                   long long rows, int cols, float *out, void *stream);
 
+/* ---- fused masked attention core (MFMA, bf16 operands, fp32 accumulate) ---------------------------------------
+ * Replaces q*scale -> bmm(q,k^T) -> masked_fill(-inf) -> softmax -> bmm(p,v) of multi_head_attention_forward
+ * (transformer_decoder/attention.py:271-387) for the PCTrans decoder under bf16 autocast.
+ *   q    [Q, N, heads*head_dim]   bfloat16      k  [S, N, heads*head_dim] bfloat16
+ *   vT   [N, heads*16, S]         bfloat16 (v transposed: one row per value channel)
+ *   mask [N, Q, S] bytes, nonzero = may not attend, shared by all heads; NULL = no mask
+ *   out  [Q, N, heads*16]         out_dtype 0 = fp32, 2 = bfloat16
+ * head_dim in {16, 32}, v_head_dim == 16, else PCT_ERR_UNSUPPORTED.  A fully masked row yields NaN (= softmax of
+ * all -inf in the reference). */
+PCT_API int pct_masked_attention_bf16(const void *q, const void *k, const void *vT, const unsigned char *mask,
+                                      int batch, int heads, int num_query, int num_key, int head_dim,
+                                      int v_head_dim, float scale, int out_dtype, void *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,8 @@ template <typename A>
 int launch_msda_backward(const void *, const int64_t *, const int64_t *, const void *, const void *, const void *,
                          int, int, int, int, int, int, int, void *, void *, void *, hipStream_t);
 void set_win_stamp_buffer(void *);
+int launch_masked_attention(const void *, const void *, const void *, const unsigned char *, int, int, int, int, int,
+                            int, float, int, void *, hipStream_t);
 int launch_add_layernorm(const float *, const float *, const float *, const float *, float, long long, int, float *,
                          hipStream_t);
 template <typename T>
@@ -207,6 +209,19 @@ int pct_add_layernorm_f32(const float *x, const float *y, const float *gamma, co
   if (!x || !gamma || !beta || !out) return PCT_ERR_BAD_ARG;
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15u) return PCT_ERR_ALIGNMENT;
   return pct::launch_add_layernorm(x, y, gamma, beta, eps, rows, cols, out, static_cast<hipStream_t>(stream));
+}
+
+int pct_masked_attention_bf16(const void *q, const void *k, const void *vT, const unsigned char *mask, int batch,
+                              int heads, int num_query, int num_key, int head_dim, int v_head_dim, float scale,
+                              int out_dtype, void *out, void *stream)
+{
+  if (batch < 0 || heads <= 0 || num_query < 0 || num_key <= 0) return PCT_ERR_BAD_ARG;
+  if (batch == 0 || num_query == 0) return PCT_OK;
+  if (!q || !k || !vT || !out) return PCT_ERR_BAD_ARG;
+  if (((uintptr_t)q | (uintptr_t)k) & 15u) return PCT_ERR_ALIGNMENT;
+  if (((uintptr_t)vT | (uintptr_t)out) & 7u) return PCT_ERR_ALIGNMENT;
+  return pct::launch_masked_attention(q, k, vT, mask, batch, heads, num_query, num_key, head_dim, v_head_dim, scale,
+                                      out_dtype, out, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

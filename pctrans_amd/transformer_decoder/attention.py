@@ -18,6 +18,8 @@ import torch
 from torch import Tensor, nn
 from torch.nn import functional as F
 
+from .. import fused_ops
+
 
 def attention_core(q: Tensor, k: Tensor, v: Tensor, num_heads: int, attn_mask: Optional[Tensor] = None,
                    key_padding_mask: Optional[Tensor] = None, dropout_p: float = 0.0, training: bool = False,
@@ -32,6 +34,11 @@ def attention_core(q: Tensor, k: Tensor, v: Tensor, num_heads: int, attn_mask: O
     hd, vhd = E // num_heads, Ev // num_heads
     assert hd * num_heads == E, "embed_dim must be divisible by num_heads"
     assert k.shape[1] == N and v.shape[0] == S and v.shape[1] == N
+
+    if fused_ops.masked_attention_supported(q, k, v, num_heads, attn_mask, key_padding_mask, dropout_p, training,
+                                            need_weights):
+        # one MFMA kernel: scores, mask, online softmax and P.V never leave the registers
+        return fused_ops.masked_attention(q, k, v, num_heads, attn_mask), None
 
     qh = (q * (float(hd) ** -0.5)).reshape(L, N, num_heads, hd).permute(1, 2, 0, 3)      # [N, h, L, hd]
     kh = k.reshape(S, N, num_heads, hd).permute(1, 2, 3, 0)                               # [N, h, hd, S]

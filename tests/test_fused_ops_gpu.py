@@ -57,3 +57,65 @@ def test_encoder_layer_fused_equals_unfused():
         a = layer(src, pos, ref, shapes, starts)                      # fused kernels
     b = layer(src.clone().requires_grad_(), pos, ref, shapes, starts)  # torch expressions + unfused op
     assert float((a - b).abs().max()) < 2e-4
+
+
+# ---- fused masked attention (MFMA) -------------------------------------------------------------------------------
+def _attn_reference(q, k, v, heads, mask):
+    """fp32 math on the bf16-valued inputs: softmax(mask(q k^T * hd^-0.5)) v per head."""
+    L, N, E = q.shape
+    S, Ev = k.shape[0], v.shape[2]
+    hd, vd = E // heads, Ev // heads
+    qh = q.float().reshape(L, N, heads, hd).permute(1, 2, 0, 3)
+    kh = k.float().reshape(S, N, heads, hd).permute(1, 2, 3, 0)
+    vh = v.float().reshape(S, N, heads, vd).permute(1, 2, 0, 3)
+    s = torch.matmul(qh, kh) * hd ** -0.5
+    if mask is not None:
+        s = s.masked_fill(mask, float("-inf"))
+    return torch.matmul(torch.softmax(s, -1), vh).permute(2, 0, 1, 3).reshape(L, N, Ev)
+
+
+@pytest.mark.parametrize("L,S,N,E,masked", [
+    (100, 4096, 2, 256, True), (100, 1024, 3, 256, True), (100, 256, 2, 256, True), (300, 374, 2, 256, True),
+    (100, 100, 4, 128, False), (37, 50, 1, 256, True), (16, 32, 1, 128, False),
+])
+def test_masked_attention_mfma(L, S, N, E, masked):
+    from pctrans_amd import fused_ops
+    torch.manual_seed(L + S)
+    heads = 8
+    q = torch.randn(L, N, E, device="cuda").bfloat16()
+    k = torch.randn(S, N, E, device="cuda").bfloat16()
+    v = torch.randn(S, N, 128, device="cuda").bfloat16()
+    mask = None
+    if masked:
+        mask = torch.rand(N, 1, L, S, device="cuda") < 0.7
+        mask[..., 0] = False                               # no fully masked row
+        mask[0, 0, 1, :] = True
+        mask[0, 0, 1, S - 1] = False                       # a row whose only live key is the very last one
+    assert fused_ops.masked_attention_supported(q, k, v, heads, mask, None, 0.0, False, False)
+    got = fused_ops.masked_attention(q, k, v, heads, mask).float()
+    want = _attn_reference(q, k, v, heads, mask)
+    # P is rounded to bf16 before P.V (as under autocast) and the output is bf16: 2^-8 relative + accumulation
+    err = (got - want).abs()
+    assert float(err.max()) < 3e-2 and float(err.mean()) < 3e-3, (float(err.max()), float(err.mean()))
+
+
+def test_attention_core_dispatches_to_mfma_kernel_and_matches_torch_path():
+    from pctrans_amd.transformer_decoder.attention import attention_core
+    torch.manual_seed(3)
+    L, S, N = 100, 1024, 2
+    q = torch.randn(L, N, 256, device="cuda").bfloat16()
+    k = torch.randn(S, N, 256, device="cuda").bfloat16()
+    v = torch.randn(S, N, 128, device="cuda").bfloat16()
+    mask = torch.rand(N, 1, L, S, device="cuda") < 0.5
+    mask[..., 0] = False
+    with torch.no_grad():
+        a, _ = attention_core(q, k, v, 8, attn_mask=mask)                 # MFMA kernel
+    b, _ = attention_core(q.float(), k.float(), v.float(), 8, attn_mask=mask)   # torch path (fp32 inputs)
+    assert a.dtype == torch.bfloat16
+    assert float((a.float() - b).abs().max()) < 3e-2
+    # fully masked row -> NaN in both
+    mask2 = mask.clone()
+    mask2[1, 0, 5, :] = True
+    with torch.no_grad():
+        c, _ = attention_core(q, k, v, 8, attn_mask=mask2)
+    assert torch.isnan(c[5, 1]).all() and torch.isfinite(c[4, 1]).all()
