@@ -170,7 +170,7 @@ def main():
                 "queries": args.queries, "parallelism": "dp%d (images sharded, no data-path collective)" % world,
             },
             "roofline": {
-                "kernel": "msda_forward_kernel<f32> (MSDeformAttn forward)",
+                "kernel": "pct::msda_forward_dpp_kernel<float,16,4,qmajor,fused> (MSDeformAttn forward incl. softmax + location math)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                 "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_ms, "launches_timed": len(fwd),

@@ -59,14 +59,15 @@ def masked_attention_supported(q, k, v, num_heads, attn_mask, key_padding_mask, 
     return True
 
 
-def masked_attention(q, k, v, num_heads, attn_mask=None):
+def masked_attention(q, k, v, num_heads, attn_mask=None, v_t=None):
     """softmax(mask(q k^T / sqrt(head_dim))) v per head: q [L,N,E], k [S,N,E], v [S,N,Ev] bf16 -> [L,N,Ev] bf16.
-    attn_mask: None | bool [N,1,L,S] | bool [L,S], True = may not attend."""
+    attn_mask: None | bool [N,1,L,S] | bool [L,S], True = may not attend.  `v_t` [N, Ev, S] may be given instead of v."""
     L, N, E = q.shape
-    S, Ev = k.shape[0], v.shape[2]
+    S = k.shape[0]
     hd = E // num_heads
     qc, kc = q.contiguous(), k.contiguous()
-    vT = v.permute(1, 2, 0).contiguous()                                  # [N, Ev, S]
+    vT = v_t.contiguous() if v_t is not None else v.permute(1, 2, 0).contiguous()   # [N, Ev, S]
+    Ev = vT.shape[1]
     m = None
     if attn_mask is not None:
         m = attn_mask.expand(N, L, S) if attn_mask.dim() == 2 else attn_mask.reshape(N, L, S)

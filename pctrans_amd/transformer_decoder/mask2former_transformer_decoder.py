@@ -32,26 +32,32 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from .. import dynamic_mask_head as dmh
+from .. import fused_ops
 from ..layers import Conv2d, c2_xavier_fill, get_norm
 from .attention import MultiheadAttention
 from .position_encoding import PositionEmbeddingSine
 
 
+_SINE_TABLES = {}
+
+
 def gen_sineembed_for_position(pos_tensor, temperature=20):
-    """[Q, N, 2k] normalised (x, y) points -> [Q, N, 256k] sine embedding, (y, x) order per point."""
-    scale = 2 * math.pi
-    dim_t = torch.arange(128, dtype=torch.float32, device=pos_tensor.device)
-    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / 128)
+    """[Q, N, 2k] normalised (x, y) points -> [Q, N, 256k] sine embedding, (y, x) order per point.
 
-    def emb(coord):
-        a = (coord * scale)[:, :, None] / dim_t
-        return torch.stack((a[:, :, 0::2].sin(), a[:, :, 1::2].cos()), dim=3).flatten(2)
-
-    pos = []
-    for i in range(pos_tensor.shape[-1] // 2):
-        pos.append(emb(pos_tensor[:, :, 2 * i + 1]))
-        pos.append(emb(pos_tensor[:, :, 2 * i]))
-    return torch.cat(pos, dim=2)
+    Element i of each 128-wide block is sin(c * 2pi / T^(2(i//2)/128)) for even i and cos(...) for odd i
+    (mask2former_transformer_decoder.py:21-39); cos(a) is evaluated as sin(a + pi/2) so that the whole embedding is one
+    fused multiply-add and one sin instead of ~14 small kernels (difference <= 1 ulp of the argument, ~5e-7)."""
+    key = (pos_tensor.device, temperature)
+    tab = _SINE_TABLES.get(key)
+    if tab is None:
+        i = torch.arange(128, dtype=torch.float32, device=pos_tensor.device)
+        dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / 128)
+        tab = _SINE_TABLES[key] = ((2 * math.pi) / dim_t, (i % 2) * (math.pi / 2))
+    freq, phase = tab
+    k = pos_tensor.shape[-1] // 2
+    Q, N = pos_tensor.shape[:2]
+    yx = pos_tensor.reshape(Q, N, k, 2).flip(-1)                        # (y, x) per point
+    return torch.sin(torch.addcmul(phase, yx.unsqueeze(-1).float(), freq)).reshape(Q, N, k * 256)
 
 
 def inverse_sigmoid(x, eps=1e-3):
@@ -67,6 +73,14 @@ def _get_activation_fn(activation):
     if activation == "glu":
         return F.glu
     raise RuntimeError(F"activation should be relu/gelu, not {activation}.")
+
+
+def _lp(x):
+    """Under autocast every nn.Linear casts its fp32 input to the autocast dtype; when the same tensor feeds several
+    Linears do that cast once (identical values, fewer launches).  No-op outside autocast."""
+    if x is not None and x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled("cuda"):
+        return x.to(torch.get_autocast_dtype("cuda"))
+    return x
 
 
 def _xavier_all(module):
@@ -90,9 +104,10 @@ class SelfAttentionLayer(nn.Module):
 
     def forward_post(self, tgt, tgt_mask: Optional[Tensor] = None, tgt_key_padding_mask: Optional[Tensor] = None,
                      query_pos: Optional[Tensor] = None):
-        q = self.sa_qcontent_proj(tgt) + self.sa_qpos_proj(query_pos)
-        k = self.sa_kcontent_proj(tgt) + self.sa_kpos_proj(query_pos)
-        v = self.sa_v_proj(tgt)
+        t, qp = _lp(tgt), _lp(query_pos)
+        q = self.sa_qcontent_proj(t) + self.sa_qpos_proj(qp)
+        k = self.sa_kcontent_proj(t) + self.sa_kpos_proj(qp)
+        v = self.sa_v_proj(t)
         tgt2 = self.self_attn(q, k, value=v, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
         return self.norm1(tgt + self.dropout1(tgt2))
 
@@ -123,8 +138,21 @@ class CrossAttentionLayer(nn.Module):
 
         q = self.ca_qcontent_proj(tgt)
         k = self.ca_kcontent_proj(memory)
-        v = self.ca_v_proj(memory)
         k_pos = self.ca_kpos_proj(pos)
+        fused = (memory_key_padding_mask is None and k.is_cuda and k.dtype == torch.bfloat16
+                 and not (torch.is_grad_enabled() and (tgt.requires_grad or memory.requires_grad))
+                 and C // h == 16 and self.cross_attn.dropout == 0.0
+                 and (memory_mask is None or (memory_mask.dtype == torch.bool
+                                              and tuple(memory_mask.shape) == (bs, 1, Q, hw))))
+        if fused:
+            # V^T [N, C, HW] straight out of the projection GEMM (W . memory^T + b): the MFMA attention kernel reads
+            # value rows per channel, so no [HW, N, C] -> [N, C, HW] transpose pass is needed
+            w = self.ca_v_proj.weight
+            v_t = torch.baddbmm(self.ca_v_proj.bias.view(1, C, 1), w.unsqueeze(0).expand(bs, C, C),
+                                memory.permute(1, 2, 0))
+            v = None
+        else:
+            v = self.ca_v_proj(memory)
         if is_first:          # first layer: the learned query position also enters the content half (:150-156)
             q_pos = self.ca_qpos_proj(query_pos)
             q = q + q_pos
@@ -137,8 +165,14 @@ class CrossAttentionLayer(nn.Module):
         q = torch.cat([q.view(Q, bs, h, hd), q_side.view(Q, bs, h, hd)], dim=3).view(Q, bs, 2 * C)
         k = torch.cat([k.view(hw, bs, h, hd), k_pos.view(hw, bs, h, hd)], dim=3).view(hw, bs, 2 * C)
 
-        tgt2 = self.cross_attn(query=q, key=k, value=v, attn_mask=memory_mask,
-                               key_padding_mask=memory_key_padding_mask)[0]
+        if fused and q.dtype == torch.bfloat16 and v_t.dtype == torch.bfloat16:
+            core = fused_ops.masked_attention(q, k, None, h, memory_mask, v_t=v_t)
+            tgt2 = self.cross_attn.out_proj(core)
+        else:
+            if v is None:
+                v = v_t.permute(2, 0, 1)
+            tgt2 = self.cross_attn(query=q, key=k, value=v, attn_mask=memory_mask,
+                                   key_padding_mask=memory_key_padding_mask)[0]
         return self.norm2(tgt + self.dropout2(tgt2))
 
     forward = forward_post
@@ -344,14 +378,15 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             size_list.append(x[i].shape[-2:])
             p = self.pe_layer(x[i], None).flatten(2)
             s = self.input_proj[i](x[i]).flatten(2) + self.level_embed.weight[i][None, :, None]
-            pos.append(p.permute(2, 0, 1))            # NxCxHW -> HWxNxC
-            src.append(s.permute(2, 0, 1))
+            pos.append(_lp(p.permute(2, 0, 1)))       # NxCxHW -> HWxNxC (each level feeds 3 layers' projections)
+            src.append(_lp(s.permute(2, 0, 1)))
         bs = src[0].shape[1]
 
-        query_embed = self.query_embed.weight.unsqueeze(1).repeat(1, bs, 1)       # Q x N x C
+        query_embed = _lp(self.query_embed.weight.unsqueeze(1).repeat(1, bs, 1))  # Q x N x C
         output = self.query_feat.weight.unsqueeze(1).repeat(1, bs, 1)
 
         predictions_mask, outputs_coords, indices_list = [], [], []
+        out_lp = None
         reference_points = self.ref_point_head(query_embed).sigmoid()
         ref_points = [reference_points]
 
@@ -371,7 +406,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         for i in range(self.num_layers):
             query_sine_embed = gen_sineembed_for_position(reference_points)
             if i > 0:
-                query_sine_embed = query_sine_embed * self.query_scale(output)
+                query_sine_embed = query_sine_embed * self.query_scale(out_lp)
 
             level_index = i % self.num_feature_levels
             # a query whose mask rules out every pixel attends everywhere instead (:561)
@@ -383,14 +418,15 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
                 output, tgt_mask=None, tgt_key_padding_mask=None, query_pos=query_embed)
             output = self.transformer_ffn_layers[i](output)
 
+            out_lp = _lp(output)                       # shared by point_embed / controller (/ next query_scale)
             # iterative reference-point update (gradient flows through the new points only)
-            new_reference_points = (self.point_embed(output) + inverse_sigmoid(reference_points)).sigmoid()
+            new_reference_points = (self.point_embed(out_lp) + inverse_sigmoid(reference_points)).sigmoid()
             if i != self.num_layers - 1:
                 ref_points.append(new_reference_points)
             reference_points = new_reference_points.detach()
 
             outputs_mask, attn_mask = self.dynamic_mask_with_coords(
-                mask_feat, new_reference_points, self.controller(output), mask_feat_stride=4,
+                mask_feat, new_reference_points, self.controller(out_lp), mask_feat_stride=4,
                 rel_coord=self.rel_coord, attn_mask_target_size=size_list[(i + 1) % self.num_feature_levels])
             if targets is not None:
                 indices = criterion.matcher({"pred_masks": outputs_mask}, targets)

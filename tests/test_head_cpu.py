@@ -280,3 +280,53 @@ def test_four_level_north_star_geometry(cpu_reference):
     with torch.no_grad():
         pred, mf = head(feats)
     assert mf.shape == (1, 128, 16, 16) and pred["pred_masks"].shape == (1, 4, 32, 32)
+
+
+# ---- query-contrast selection (training hook of the last decoder layer) ------------------------------------------
+def _reference_style_selection(query, emb_dist, pos_indices):
+    """mask2former_transformer_decoder.py:800-858 restated literally (list/set bookkeeping) for one batch."""
+    out = []
+    q = query.transpose(0, 1)
+    Qn = q.shape[1]
+    for b in range(q.shape[0]):
+        pos_ids = pos_indices[b][0].tolist()
+        rest_ids = list(set(range(Qn)) - set(pos_ids))
+        rest = emb_dist[b][rest_ids][:, pos_ids]
+        mdp = torch.argmax(rest, dim=1).tolist()
+        mdp = torch.tensor([pos_ids[i] for i in mdp])
+        for pid in pos_ids:
+            cl = [rest_ids[i] for i in torch.where(mdp == pid)[0].tolist()]
+            if not cl:
+                continue
+            neg = list(set(range(Qn)) - set(cl + [pid]))
+            out.append((b, pid, sorted(cl), sorted(neg)))
+    return out
+
+
+def test_query_contrast_selection_matches_reference_bookkeeping():
+    import random
+    from pctrans_amd.transformer_decoder import query_contrast as qc
+    torch.manual_seed(0)
+    Q, N, C = 12, 2, 16
+    output = torch.randn(Q, N, C)
+    masks = torch.randn(N, Q, 6, 5)
+    indices = [(torch.tensor([1, 4, 7]), torch.tensor([0, 1, 2])), (torch.tensor([0, 11]), torch.tensor([1, 0]))]
+    random.seed(5)
+    items_q, items_m = qc.query_contrast_items(output, masks, indices)
+    qn = output.permute(1, 0, 2)
+    emb = torch.stack([torch.cosine_similarity(qn[i].unsqueeze(1), qn[i].unsqueeze(0), dim=-1) for i in range(N)])
+    want = _reference_style_selection(output, emb, indices)
+    assert len(items_q) == len(items_m) == len(want) > 0
+    for it_q, it_m, (b, pid, cl, neg) in zip(items_q, items_m, want):
+        assert int(it_q["label"].sum()) == len(cl) and it_q["label"].numel() == len(cl) + len(neg)
+        key = output[pid, b]
+        np.testing.assert_allclose(it_q["contrast"][:len(cl), 0].numpy(), (output[cl, b] @ key).numpy(), atol=1e-5)
+        np.testing.assert_allclose(it_q["contrast"][len(cl):, 0].numpy(), (output[neg, b] @ key).numpy(), atol=1e-5)
+        n_s = len(neg) if len(cl) * 10 >= len(neg) else len(cl) * 10
+        assert it_q["aux_consin"].shape == (len(cl) + n_s, 1) and float(it_q["aux_consin"].abs().max()) <= 1 + 1e-5
+        d = qc.dice_for(masks[b])
+        np.testing.assert_allclose(it_m["contrast"][:, 0].numpy(), torch.cat([d[pid][cl], d[pid][neg]]).numpy(),
+                                   atol=1e-6)
+    # dice_for: symmetric, 1 on the diagonal up to the +1 smoothing
+    d = qc.dice_for(masks[0])
+    assert torch.allclose(d, d.t()) and float(d.diag().min()) > 0.99
