@@ -327,6 +327,8 @@ def test_query_contrast_selection_matches_reference_bookkeeping():
         d = qc.dice_for(masks[b])
         np.testing.assert_allclose(it_m["contrast"][:, 0].numpy(), torch.cat([d[pid][cl], d[pid][neg]]).numpy(),
                                    atol=1e-6)
-    # dice_for: symmetric, 1 on the diagonal up to the +1 smoothing
+    # dice_for: symmetric; exactly 1 for identical hard (0/1) masks
     d = qc.dice_for(masks[0])
-    assert torch.allclose(d, d.t()) and float(d.diag().min()) > 0.99
+    assert torch.allclose(d, d.t())
+    hard = torch.where(torch.rand(3, 4, 4) < 0.5, 50.0, -50.0)
+    assert torch.allclose(qc.dice_for(hard).diag(), torch.ones(3), atol=1e-6)
