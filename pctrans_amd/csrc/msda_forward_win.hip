@@ -31,6 +31,8 @@ constexpr int WIN_BLOCK = 256;
 constexpr int WIN_TH = 8;              // tile height in pyramid mode (tile width = TQ / 8)
 constexpr int WIN_MAXL = 8;
 
+__device__ const float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // source of the zero apron texels
+
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b)
 {
@@ -48,12 +50,13 @@ __device__ __forceinline__ unsigned dpp_u(unsigned v)
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v)
 {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, true));
 }
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v)
 {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, true);
 }
 // quad_perm control that makes every lane of a QL-lane group read lane `src` of its own group
 template <int QL, int SRC>
@@ -90,7 +93,8 @@ __device__ __forceinline__ LevelWindow read_window(const unsigned *bb, const int
   }
   lo = __builtin_amdgcn_readfirstlane(lo);
   hi = __builtin_amdgcn_readfirstlane(hi);
-  const int x0 = (int)(lo & 0xFFFFu), y0 = (int)(lo >> 16), x1 = (int)(hi & 0xFFFFu), y1 = (int)(hi >> 16);
+  const int x0 = (int)(lo & 0xFFFFu) - 1, y0 = (int)(lo >> 16) - 1;      // un-bias: origin may be -1 (apron)
+  const int x1 = (int)(hi & 0xFFFFu) - 1, y1 = (int)(hi >> 16) - 1;
   LevelWindow w;
   const bool empty = x0 > x1 || y0 > y1;
   w.x0 = x0;
@@ -220,11 +224,12 @@ __global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
       for (int k = 0; k < PPL; ++k) {
         const float h_im = sy[l][k] * Hs[l] - 0.5f, w_im = sx[l][k] * Ws[l] - 0.5f;
         const bool gate = qvalid && h_im > -1 && w_im > -1 && h_im < Hs[l] && w_im < Ws[l];
+        // gate => x0 in [-1, W-1], y0 in [-1, H-1]; the box covers all four corners INCLUDING out-of-map ones
+        // (staged as zeros: a 1-pixel apron), coordinates biased by +1 to stay unsigned
         const int y0 = gate ? (int)floorf(h_im) : 0, x0 = gate ? (int)floorf(w_im) : 0;
-        const unsigned xa = (unsigned)max(x0, 0), xb = (unsigned)min(x0 + 1, Ws[l] - 1);
-        const unsigned ya = (unsigned)max(y0, 0), yb = (unsigned)min(y0 + 1, Hs[l] - 1);
+        const unsigned xa = (unsigned)(x0 + 1), ya = (unsigned)(y0 + 1);
         lo = gate ? pk_min(lo, xa | (ya << 16)) : lo;
-        hi = gate ? pk_max(hi, xb | (yb << 16)) : hi;
+        hi = gate ? pk_max(hi, (xa + 1) | ((ya + 1) << 16)) : hi;
       }
       lo = wave_reduce_pk<true>(lo);
       hi = wave_reduce_pk<false>(hi);
@@ -271,15 +276,25 @@ __global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
       if (in_lds[l] && wsize[l] > 0) {
         const float inv_w = 1.0f / (float)wwid[l];
         const int n16 = wsize[l] * QL;
-        const ST *vlev = vimg + (long long)(St[l] + wy0[l] * Ws[l] + wx0[l]) * MD;
+        const ST *vlev = vimg + (long long)St[l] * MD;
         unsigned char *dst = pool + (size_t)wbase[l] * PXB;
-#pragma unroll 2
-        for (int i = tid; i < n16; i += WIN_BLOCK) {
-          const int px = i / QL, cc = i & (QL - 1);
-          const int r = (int)(((float)px + 0.5f) * inv_w);
-          const int col = px - r * wwid[l];
-          const v16 v = *reinterpret_cast<const v16 *>(vlev + (long long)(r * Ws[l] + col) * MD + cc * VEC);
-          *reinterpret_cast<v16 *>(dst + (size_t)i * 16) = v;
+        // LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, so every piece of every level is in flight at
+        // once and the only wait is the barrier below.  The LDS address of a piece is wave-uniform base + lane*16,
+        // which is exactly dst + i*16 for i = wave*64 + lane + it*256; the global source is per lane (apron lanes
+        // read a 16-byte zero constant instead of the map).
+        for (int it = 0; it * WIN_BLOCK < n16; ++it) {
+          const int i = it * WIN_BLOCK + tid;
+          if (i < n16) {
+            const int px = i / QL, cc = i & (QL - 1);
+            const int r = (int)(((float)px + 0.5f) * inv_w);
+            const int y = wy0[l] + r, x = wx0[l] + px - r * wwid[l];
+            const bool inside = y >= 0 && y < Hs[l] && x >= 0 && x < Ws[l];
+            const ST *src = inside ? vlev + (long long)(y * Ws[l] + x) * MD + cc * VEC
+                                   : reinterpret_cast<const ST *>(g_zero16);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src),
+                (__attribute__((address_space(3))) void *)(dst + (size_t)(it * WIN_BLOCK + (tid & ~63)) * 16), 16, 0, 0);
+          }
         }
       }
     }
@@ -298,6 +313,7 @@ __global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
     for (int l = 0; l < L; ++l) {
       const int H = Hs[l], W = Ws[l];
       const bool lds = in_lds[l] != 0;
+      const unsigned row_bytes = (unsigned)(wwid[l] * PXB);
       // owner side: geometry of my points on this level (corner offsets + bilinear * attention weights)
       int o1[PPL], o2[PPL], o3[PPL], o4[PPL];
       float g1[PPL], g2[PPL], g3[PPL], g4[PPL];
@@ -317,15 +333,18 @@ __global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
         g2[k] = hh * lw * wgt;
         g3[k] = lh * hw * wgt;
         g4[k] = lh * lw * wgt;
-        // LDS: byte offsets into the pool, out-of-map corners -> the zero pixel (offset 0).
-        // global: element offsets from this image/head base, out-of-map corners -> -1 (load element 0, select 0).
-        const int a = lds ? (wbase[l] + (y0 - wy0[l]) * wwid[l] + (x0 - wx0[l])) * PXB : (St[l] + y0 * W + x0) * MD;
-        const int dx = lds ? PXB : MD, dy = lds ? wwid[l] * PXB : W * MD;
-        const int none = lds ? 0 : -1;
-        o1[k] = ok1 ? a : none;
-        o2[k] = ok2 ? a + dx : none;
-        o3[k] = ok3 ? a + dy : none;
-        o4[k] = ok4 ? a + dy + dx : none;
+        if (lds) {
+          // all four corners lie inside the staged window (out-of-map ones are zeros): one offset is enough
+          o1[k] = (wbase[l] + (y0 - wy0[l]) * wwid[l] + (x0 - wx0[l])) * PXB;
+          o2[k] = o3[k] = o4[k] = 0;
+        } else {
+          // element offsets from this image/head base, out-of-map corners -> -1 (load element 0, select 0)
+          const int a = (St[l] + y0 * W + x0) * MD;
+          o1[k] = ok1 ? a : -1;
+          o2[k] = ok2 ? a + MD : -1;
+          o3[k] = ok3 ? a + W * MD : -1;
+          o4[k] = ok4 ? a + W * MD + MD : -1;
+        }
       }
 
       // consumer side: every lane walks all P points, taking point p's geometry from its owner lane by DPP
@@ -334,33 +353,48 @@ __global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
         constexpr bool LDS = decltype(lds_c)::value;
         constexpr int k = p / QL;
         constexpr int ctrl = BcastCtrl<QL, p % QL>::value;
-        const int a1 = dpp_i<ctrl>(o1[k]), a2 = dpp_i<ctrl>(o2[k]);
-        const int a3 = dpp_i<ctrl>(o3[k]), a4 = dpp_i<ctrl>(o4[k]);
+        const int a1 = dpp_i<ctrl>(o1[k]);
+        int a2 = 0, a3 = 0, a4 = 0;
         const float w1 = dpp_f<ctrl>(g1[k]), w2 = dpp_f<ctrl>(g2[k]);
         const float w3 = dpp_f<ctrl>(g3[k]), w4 = dpp_f<ctrl>(g4[k]);
         v16 v1, v2, v3, v4;
         if constexpr (LDS) {
-          v1 = *reinterpret_cast<const v16 *>(pool_lane + (unsigned)a1);
-          v2 = *reinterpret_cast<const v16 *>(pool_lane + (unsigned)a2);
-          v3 = *reinterpret_cast<const v16 *>(pool_lane + (unsigned)a3);
-          v4 = *reinterpret_cast<const v16 *>(pool_lane + (unsigned)a4);
+          const unsigned char *pa = pool_lane + (unsigned)a1, *pb = pa + row_bytes;
+          v1 = *reinterpret_cast<const v16 *>(pa);
+          v2 = *reinterpret_cast<const v16 *>(pa + PXB);            // immediate ds_read offset
+          v3 = *reinterpret_cast<const v16 *>(pb);
+          v4 = *reinterpret_cast<const v16 *>(pb + PXB);
         } else {
+          a2 = dpp_i<ctrl>(o2[k]);
+          a3 = dpp_i<ctrl>(o3[k]);
+          a4 = dpp_i<ctrl>(o4[k]);
           v1 = *reinterpret_cast<const v16 *>(vlane + max(a1, 0));
           v2 = *reinterpret_cast<const v16 *>(vlane + max(a2, 0));
           v3 = *reinterpret_cast<const v16 *>(vlane + max(a3, 0));
           v4 = *reinterpret_cast<const v16 *>(vlane + max(a4, 0));
         }
+        // explicit 2-wide FMA chains (v_pk_fma_f32): 4 packed FMAs per channel pair, straight into the accumulator
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 ww1 = {w1, w1}, ww2 = {w2, w2}, ww3 = {w3, w3}, ww4 = {w4, w4};
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          float x1 = Traits<T>::to_acc(v1[e]), x2 = Traits<T>::to_acc(v2[e]);
-          float x3 = Traits<T>::to_acc(v3[e]), x4 = Traits<T>::to_acc(v4[e]);
+        for (int e = 0; e < VEC; e += 2) {
+          f32x2 x1 = {Traits<T>::to_acc(v1[e]), Traits<T>::to_acc(v1[e + 1])};
+          f32x2 x2 = {Traits<T>::to_acc(v2[e]), Traits<T>::to_acc(v2[e + 1])};
+          f32x2 x3 = {Traits<T>::to_acc(v3[e]), Traits<T>::to_acc(v3[e + 1])};
+          f32x2 x4 = {Traits<T>::to_acc(v4[e]), Traits<T>::to_acc(v4[e + 1])};
           if constexpr (!LDS) {
-            x1 = a1 < 0 ? 0.f : x1;
-            x2 = a2 < 0 ? 0.f : x2;
-            x3 = a3 < 0 ? 0.f : x3;
-            x4 = a4 < 0 ? 0.f : x4;
+            if (a1 < 0) x1 = f32x2{0.f, 0.f};
+            if (a2 < 0) x2 = f32x2{0.f, 0.f};
+            if (a3 < 0) x3 = f32x2{0.f, 0.f};
+            if (a4 < 0) x4 = f32x2{0.f, 0.f};
           }
-          acc[e] += w1 * x1 + w2 * x2 + w3 * x3 + w4 * x4;
+          f32x2 t = {acc[e], acc[e + 1]};
+          t = __builtin_elementwise_fma(ww1, x1, t);
+          t = __builtin_elementwise_fma(ww2, x2, t);
+          t = __builtin_elementwise_fma(ww3, x3, t);
+          t = __builtin_elementwise_fma(ww4, x4, t);
+          acc[e] = t[0];
+          acc[e + 1] = t[1];
         }
       };
       if (lds) {
