@@ -21,8 +21,8 @@ int launch_masked_attention(const void *, const void *, const void *, const unsi
 int launch_add_layernorm(const float *, const float *, const float *, const float *, float, long long, int, float *,
                          hipStream_t);
 template <typename T>
-int launch_msda_forward_dpp(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
-                            int, int, int, int, void *, hipStream_t, const float *, long long);
+int launch_msda_forward_special(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int,
+                                int, int, int, int, int, void *, hipStream_t, const float *, long long);
 int launch_dyn_mask_head(const float *, const float *, const float *, int, int, int, int, int, int, int, int, int,
                          int, void *, unsigned char *, hipStream_t);
 }  // namespace pct
@@ -150,7 +150,7 @@ int pct_ms_deform_attn_fused_forward_f32(const float *value, const int64_t *spat
   if (batch == 0 || num_query == 0) return PCT_OK;
   if (!output || !ref_points || ref_batch_stride < 0) return PCT_ERR_BAD_ARG;
   if (((uintptr_t)output | (uintptr_t)ref_points) & 3u) return PCT_ERR_ALIGNMENT;
-  const int r = pct::launch_msda_forward_dpp<float>(value, spatial_shapes, level_start, offsets, attn_logits, batch,
+  const int r = pct::launch_msda_forward_special<float>(value, spatial_shapes, level_start, offsets, attn_logits, batch,
                                                     spatial_size, num_heads, channels, num_levels, num_query,
                                                     num_point, output, static_cast<hipStream_t>(stream), ref_points,
                                                     ref_batch_stride);

@@ -193,23 +193,47 @@ __global__ __launch_bounds__(FWD_BLOCK) void msda_forward_kernel(
 // specialised kernels for PCTrans' geometry; each returns -100 when it does not cover the call
 template <typename T>
 int launch_msda_forward_win(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
-                            int, int, int, int, void *, hipStream_t);   // msda_forward_win.hip (LDS windows)
+                            int, int, int, int, void *, hipStream_t, const float *, long long);   // msda_forward_win.hip
 template <typename T>
 int launch_msda_forward_dpp(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
                             int, int, int, int, void *, hipStream_t, const float *, long long);   // msda_forward_dpp.hip
 
-// PCT_MSDA_KERNEL = dpp (default) | win | generic : development A/B switch, read once
-static int kernel_choice()
+// Kernel choice for PCTrans' geometry.  Default "auto": the windowed-LDS kernel when the queries are the pyramid's
+// own pixels (Lq == S: neighbouring queries sample neighbouring texels, the case it is built for) and the problem fills
+// its persistent grid, else the quad-owner kernel.  PCT_MSDA_KERNEL = auto | win | dpp | generic (development A/B).
+int msda_kernel_choice()
 {
   static const int v = [] {
     const char *e = getenv("PCT_MSDA_KERNEL");
     if (!e) return 0;
     if (e[0] == 'w') return 1;
+    if (e[0] == 'd') return 3;
     if (e[0] == 'g') return 2;
     return 0;
   }();
   return v;
 }
+
+// shared by the plain and the fused entry points: -100 = geometry not covered by the specialised kernels
+template <typename T>
+int launch_msda_forward_special(const void *value, const int64_t *shapes, const int64_t *starts, const void *loc,
+                                const void *attn, int N, int S, int M, int D, int L, int Lq, int P, void *out,
+                                hipStream_t stream, const float *ref, long long ref_batch_stride)
+{
+  const int choice = msda_kernel_choice();
+  if (choice == 2) return -100;
+  int rc = -100;
+  if (choice == 1 || (choice == 0 && Lq == S))
+    rc = launch_msda_forward_win<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream, ref,
+                                    ref_batch_stride);
+  if (rc == -100)
+    rc = launch_msda_forward_dpp<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream, ref,
+                                    ref_batch_stride);
+  return rc;
+}
+template int launch_msda_forward_special<float>(const void *, const int64_t *, const int64_t *, const void *,
+                                                const void *, int, int, int, int, int, int, int, void *, hipStream_t,
+                                                const float *, long long);
 
 // ---- host-side launcher ---------------------------------------------------------------------------------
 template <typename T>
@@ -220,14 +244,9 @@ int launch_msda_forward(const void *value, const int64_t *shapes, const int64_t 
   using A = typename Traits<T>::acc_t;
   using ST = typename Traits<T>::store_t;
   if constexpr (sizeof(A) == 4) {
-    const int choice = kernel_choice();
-    if (choice != 2) {
-      int rc = -100;
-      if (choice == 1) rc = launch_msda_forward_win<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream);
-      if (rc == -100)
-        rc = launch_msda_forward_dpp<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream, nullptr, 0);
-      if (rc != -100) return rc;
-    }
+    const int rc = launch_msda_forward_special<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream,
+                                                  nullptr, 0);
+    if (rc != -100) return rc;
   }
   constexpr int VECW = 16 / (int)sizeof(ST);                    // channels in one 16-byte lane load
   const bool aligned16 = (((uintptr_t)value | (uintptr_t)out) & 15u) == 0 &&

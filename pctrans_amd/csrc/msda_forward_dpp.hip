@@ -110,9 +110,9 @@ __global__ __launch_bounds__(1024) void msda_forward_dpp_kernel(
     sm_inv = 1.f / sum;
   }
 
-  float acc[VEC];
+  float acc[VEC], acc2[VEC], acc3[VEC], acc4[VEC];
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  for (int e = 0; e < VEC; ++e) acc[e] = acc2[e] = acc3[e] = acc4[e] = 0.f;
 
   // software pipeline over levels: my points of level l+1 are in flight while level l is gathered
   float nx[PPL], ny[PPL], nw[PPL];
@@ -196,12 +196,13 @@ __global__ __launch_bounds__(1024) void msda_forward_dpp_kernel(
       const i32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)a4, 0, 0);
       const vec_t<ST, VEC> v1 = __builtin_bit_cast(vec_t<ST, VEC>, r1), v2 = __builtin_bit_cast(vec_t<ST, VEC>, r2);
       const vec_t<ST, VEC> v3 = __builtin_bit_cast(vec_t<ST, VEC>, r3), v4 = __builtin_bit_cast(vec_t<ST, VEC>, r4);
+      // one accumulator per corner: independent FMA chains (no back-to-back dependent FMAs)
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        float t = fmaf(w1, Traits<T>::to_acc(v1[e]), acc[e]);
-        t = fmaf(w2, Traits<T>::to_acc(v2[e]), t);
-        t = fmaf(w3, Traits<T>::to_acc(v3[e]), t);
-        acc[e] = fmaf(w4, Traits<T>::to_acc(v4[e]), t);
+        acc[e] = fmaf(w1, Traits<T>::to_acc(v1[e]), acc[e]);
+        acc2[e] = fmaf(w2, Traits<T>::to_acc(v2[e]), acc2[e]);
+        acc3[e] = fmaf(w3, Traits<T>::to_acc(v3[e]), acc3[e]);
+        acc4[e] = fmaf(w4, Traits<T>::to_acc(v4[e]), acc4[e]);
       }
     };
     [&]<int... Ps>(std::integer_sequence<int, Ps...>) {
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(1024) void msda_forward_dpp_kernel(
   if (active) {
     vec_t<ST, VEC> o;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) o[e] = Traits<T>::from_acc(acc[e]);
+    for (int e = 0; e < VEC; ++e) o[e] = Traits<T>::from_acc((acc[e] + acc2[e]) + (acc3[e] + acc4[e]));
     *reinterpret_cast<vec_t<ST, VEC> *>(out + rec * D + c * VEC) = o;
   }
 }

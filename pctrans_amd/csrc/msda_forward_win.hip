@@ -21,6 +21,9 @@
 //     the global gather for that level only, still with owner-computed geometry;
 //   * persistent grid: WG g serves XCD (g % 8); each XCD walks one contiguous chunk of the (b, tile, m) items with the
 //     8 heads of a tile adjacent, so the 512-B pixel lines a tile's heads share are fetched into one L2.
+#include <math.h>
+#include <stdlib.h>
+
 #include <utility>
 
 #include "msda_common.hpp"
@@ -104,18 +107,28 @@ __device__ __forceinline__ LevelWindow read_window(const unsigned *bb, const int
   return w;
 }
 
-template <typename T, int D, int L, int P, bool STAMP = false>
+// NS = query slots per lane: one work item covers NS * (256 / QL) queries, so the per-item work (bounding boxes,
+// window set-up, staging, barriers) is amortised over NS gathers.
+// FUSED: `loc` holds raw sampling offsets, `attn` raw attention logits, `ref` the reference points; the kernel forms
+// location = ref[q, l] + offset / (W_l, H_l) and weight = softmax over the record's L*P logits itself
+// (ops/modules/ms_deform_attn.py:100-109), as msda_forward_dpp.hip does.
+template <typename T, int D, int L, int P, int NS, bool FUSED, bool STAMP = false>
 __global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
     const typename Traits<T>::store_t *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn, const int N,
     const int S, const int M, const int Lq, const int pyramid, const int pool_px,
-    typename Traits<T>::store_t *__restrict__ out, unsigned long long *__restrict__ stamps = nullptr)
+    typename Traits<T>::store_t *__restrict__ out, const float *__restrict__ ref, const long long ref_batch_stride,
+    unsigned long long *__restrict__ stamps = nullptr)
 {
   using ST = typename Traits<T>::store_t;
   constexpr int VEC = 16 / (int)sizeof(ST);       // channels per lane
   constexpr int QL = D / VEC;                     // lanes per (query, head) = per head-pixel
-  constexpr int TQ = WIN_BLOCK / QL;              // queries per tile
-  constexpr int TW = TQ / WIN_TH;                 // tile width in pyramid mode
+  constexpr int TQ = WIN_BLOCK / QL;              // queries per slot
+  // pyramid-mode tile: TW pixels wide, SH rows per slot, NS slots stacked -> 8x8 (NS=1), 8x16 (NS=2), 16x16 (NS=4)
+  // for QL = 4 (squarer tiles = smaller halo per query)
+  constexpr int TW = (TQ / WIN_TH) * (NS >= 4 ? 2 : 1);
+  constexpr int SH = TQ / TW;                     // rows per slot
+  constexpr int THT = SH * NS;                    // tile height
   constexpr int PPL = P / QL;                     // points each lane owns per level
   constexpr int PXB = QL * 16;                    // bytes per head-pixel
   // diagnostic build only (STAMP): per-phase cycle sums of wave 0, written to a buffer nothing else reads
@@ -132,14 +145,15 @@ __global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
   };
   static_assert(D % VEC == 0 && (QL == 2 || QL == 4) && P % QL == 0 && L <= WIN_MAXL, "unsupported geometry");
   using v16 = vec_t<ST, VEC>;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned char *pool = smem_raw;                                   // pixel 0 = zeros, then the level windows
-  unsigned *bb = reinterpret_cast<unsigned *>(smem_raw + (size_t)(pool_px + 1) * PXB);   // [4 waves][L][2]
+  unsigned char *pool = smem_raw;                                   // the level windows (head-pixels of PXB bytes)
+  unsigned *bb = reinterpret_cast<unsigned *>(smem_raw + (size_t)pool_px * PXB);   // [4 waves][L][2]
 
   const int tid = threadIdx.x, wave = tid >> 6;
   const int c = tid & (QL - 1);                   // lane within the query's group
-  const int j = tid / QL;                         // query slot within the tile
+  const int j = tid / QL;                         // query position within a slot
   const int MD = M * D;
 
   // level geometry (uniform -> SGPRs) and the tile census
@@ -150,126 +164,125 @@ __global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
     Hs[l] = (int)shapes[2 * l];
     Ws[l] = (int)shapes[2 * l + 1];
     St[l] = (int)starts[l];
-    tiles_before[l + 1] = tiles_before[l] + ((Hs[l] + WIN_TH - 1) / WIN_TH) * ((Ws[l] + TW - 1) / TW);
+    tiles_before[l + 1] = tiles_before[l] + ((Hs[l] + THT - 1) / THT) * ((Ws[l] + TW - 1) / TW);
   }
-  const int T_img = pyramid ? tiles_before[L] : (Lq + TQ - 1) / TQ;
+  const int T_img = pyramid ? tiles_before[L] : (Lq + TQ * NS - 1) / (TQ * NS);
   const int items = N * T_img * M;
 
-  if (tid < QL) reinterpret_cast<vec_t<float, 4> *>(pool)[tid] = vec_t<float, 4>{0.f, 0.f, 0.f, 0.f};   // zero pixel
+  // pixels 0 and 1 of the pool are zeros: gated-out samples read them (weight 0 times a guaranteed-finite value)
+  if (tid < 2 * QL) reinterpret_cast<vec_t<float, 4> *>(pool)[tid] = vec_t<float, 4>{0.f, 0.f, 0.f, 0.f};
 
   // persistent, XCD-chunked walk over the items
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int chunk = (items + 7) / 8;
   const int item_end = min((xcd + 1) * chunk, items);
 
-  // item -> (record index of this lane's query or -1, image, head)
-  auto locate = [&](int item, int &b, int &m) -> long long {
-    m = item % M;
+  for (int item = xcd * chunk + slot0; item < item_end; item += nslots) {
+    stamp(-1);
+    const int m = item % M;
     const int bt = item / M;
     const int t = bt % T_img;
-    b = bt / T_img;
-    int q;
-    bool qvalid;
-    if (pyramid) {
+    const int b = bt / T_img;
+
+    // ---- this lane's NS queries (record index or -1) -----------------------------------------------------------
+    long long recs[NS];
+    int qidx[NS];                                                   // query index within the image (FUSED: ref row)
+    {
       int Hq = Hs[0], Wq = Ws[0], Sq = St[0], tb = 0;
+      if (pyramid) {
 #pragma unroll
-      for (int l = 1; l < L; ++l)
-        if (t >= tiles_before[l]) { Hq = Hs[l]; Wq = Ws[l]; Sq = St[l]; tb = tiles_before[l]; }
+        for (int l = 1; l < L; ++l)
+          if (t >= tiles_before[l]) { Hq = Hs[l]; Wq = Ws[l]; Sq = St[l]; tb = tiles_before[l]; }
+      }
       const int tpr = (Wq + TW - 1) / TW;
       const int tl = t - tb;
       const int ty = tl / tpr, tx = tl - ty * tpr;
-      const int qy = ty * WIN_TH + j / TW, qx = tx * TW + (j % TW);
-      qvalid = qy < Hq && qx < Wq;
-      q = Sq + qy * Wq + qx;
-    } else {
-      q = t * TQ + j;
-      qvalid = q < Lq;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        int q;
+        bool ok;
+        if (pyramid) {
+          const int qy = ty * THT + s * SH + j / TW, qx = tx * TW + (j % TW);
+          ok = qy < Hq && qx < Wq;
+          q = Sq + qy * Wq + qx;
+        } else {
+          q = (t * NS + s) * TQ + j;
+          ok = q < Lq;
+        }
+        recs[s] = ok ? ((long long)b * Lq + q) * M + m : -1;
+        qidx[s] = ok ? q : 0;
+      }
     }
-    return qvalid ? ((long long)b * Lq + q) * M + m : -1;
-  };
-  // owner loads: points p = c + k*QL of every level of record `rec` (lanes without a query load record 0)
-  auto load_points = [&](long long rec, float (&x)[L][PPL], float (&y)[L][PPL], float (&w)[L][PPL]) {
-    const long long r = rec < 0 ? 0 : rec;
-    const float *lrec = loc + r * (L * P * 2) + c * 2;
-    const float *wrec = attn + r * (L * P) + c;
+
+    // ---- pre-pass: per-level bounding box (incl. 1-pixel apron) of every corner the tile touches ---------------
+    {
+      f32x2 pxy[NS][L][PPL];
 #pragma unroll
-    for (int l = 0; l < L; ++l)
+      for (int s = 0; s < NS; ++s) {
+        const float *lrec = loc + (recs[s] < 0 ? 0 : recs[s]) * (L * P * 2) + c * 2;
+        const float *rrow = FUSED ? ref + b * ref_batch_stride + (long long)qidx[s] * (L * 2) : nullptr;
 #pragma unroll
-      for (int k = 0; k < PPL; ++k) {
-        const vec_t<float, 2> xy = *reinterpret_cast<const vec_t<float, 2> *>(lrec + (l * P + k * QL) * 2);
-        x[l][k] = xy[0];
-        y[l][k] = xy[1];
-        w[l][k] = wrec[l * P + k * QL];
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+          for (int k = 0; k < PPL; ++k) {
+            f32x2 v = *reinterpret_cast<const f32x2 *>(lrec + (l * P + k * QL) * 2);
+            if constexpr (FUSED) {
+              const f32x2 r = *reinterpret_cast<const f32x2 *>(rrow + 2 * l);
+              v = f32x2{r[0] + v[0] / (float)Ws[l], r[1] + v[1] / (float)Hs[l]};
+            }
+            pxy[s][l][k] = v;
+          }
       }
-  };
-
-  int item = xcd * chunk + slot;
-  float sx[L][PPL], sy[L][PPL], sw[L][PPL];
-  int b = 0, m = 0;
-  long long rec = -1;
-  if (item < item_end) {
-    rec = locate(item, b, m);
-    load_points(rec, sx, sy, sw);
-  }
-
-  for (; item < item_end; item += nslots) {
-    const bool qvalid = rec >= 0;
-    stamp(-1);
-
-    // ---- pre-pass: per-level bounding box of the in-map corners this tile touches ----------------------------
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-      unsigned lo = 0xFFFFFFFFu, hi = 0u;
+      for (int l = 0; l < L; ++l) {
+        unsigned lo = 0xFFFFFFFFu, hi = 0u;
 #pragma unroll
-      for (int k = 0; k < PPL; ++k) {
-        const float h_im = sy[l][k] * Hs[l] - 0.5f, w_im = sx[l][k] * Ws[l] - 0.5f;
-        const bool gate = qvalid && h_im > -1 && w_im > -1 && h_im < Hs[l] && w_im < Ws[l];
-        // gate => x0 in [-1, W-1], y0 in [-1, H-1]; the box covers all four corners INCLUDING out-of-map ones
-        // (staged as zeros: a 1-pixel apron), coordinates biased by +1 to stay unsigned
-        const int y0 = gate ? (int)floorf(h_im) : 0, x0 = gate ? (int)floorf(w_im) : 0;
-        const unsigned xa = (unsigned)(x0 + 1), ya = (unsigned)(y0 + 1);
-        lo = gate ? pk_min(lo, xa | (ya << 16)) : lo;
-        hi = gate ? pk_max(hi, (xa + 1) | ((ya + 1) << 16)) : hi;
-      }
-      lo = wave_reduce_pk<true>(lo);
-      hi = wave_reduce_pk<false>(hi);
-      if ((tid & 63) == 0) {
-        bb[(wave * L + l) * 2] = lo;
-        bb[(wave * L + l) * 2 + 1] = hi;
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int k = 0; k < PPL; ++k) {
+            const float h_im = pxy[s][l][k][1] * Hs[l] - 0.5f, w_im = pxy[s][l][k][0] * Ws[l] - 0.5f;
+            const bool gate = recs[s] >= 0 && h_im > -1 && w_im > -1 && h_im < Hs[l] && w_im < Ws[l];
+            // gate => x0 in [-1, W-1], y0 in [-1, H-1]; biased by +1 to stay unsigned; the box covers all four
+            // corners INCLUDING out-of-map ones (staged as zeros)
+            const unsigned xa = (unsigned)((int)floorf(w_im) + 1), ya = (unsigned)((int)floorf(h_im) + 1);
+            lo = gate ? pk_min(lo, xa | (ya << 16)) : lo;
+            hi = gate ? pk_max(hi, (xa + 1) | ((ya + 1) << 16)) : hi;
+          }
+        lo = wave_reduce_pk<true>(lo);
+        hi = wave_reduce_pk<false>(hi);
+        if ((tid & 63) == 0) {
+          bb[(wave * L + l) * 2] = lo;
+          bb[(wave * L + l) * 2 + 1] = hi;
+        }
       }
     }
     stamp(0);
     __syncthreads();                                               // (1) boxes visible
     stamp(1);
 
-    // ---- prefetch the next item's points: in flight underneath staging + gather of this item -----------------
-    float nx[L][PPL], ny[L][PPL], nw[L][PPL];
-    int nb = 0, nm = 0;
-    long long nrec = -1;
-    if (item + nslots < item_end) {
-      nrec = locate(item + nslots, nb, nm);
-      load_points(nrec, nx, ny, nw);
-    }
-
     // ---- windows (identical in every lane; kept in SGPRs) -------------------------------------------------------
     int wx0[L], wy0[L], wwid[L], wbase[L], wsize[L], in_lds[L];
     {
       int used = 0;
 #pragma unroll
-      for (int l = 0; l < L; ++l) {
+      for (int ll = 0; ll < L; ++ll) {
+        const int l = L - 1 - ll;       // last level first: PCTrans orders levels coarse -> fine and the finest
+                                        // level has the largest window and the most samples worth keeping in LDS
         const LevelWindow w = read_window(bb, L, l);
         wx0[l] = w.x0;
         wy0[l] = w.y0;
         wwid[l] = w.wid;
         wsize[l] = w.size;
-        in_lds[l] = used + w.size <= pool_px ? 1 : 0;
-        wbase[l] = used + 1;                                        // +1: pixel 0 is the zero pixel
+        in_lds[l] = used + w.size <= pool_px - 2 ? 1 : 0;
+        wbase[l] = used + 2;                                        // pixels 0, 1 are the zero pixels
         used += in_lds[l] ? w.size : 0;
       }
     }
-
     stamp(2);
-    // ---- stage the boxes that fit: coalesced 16-B loads, QL lanes per head-pixel ------------------------------
+
+    // ---- stage the boxes that fit by LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, every piece of every
+    // level in flight at once; LDS address of a piece = wave-uniform base + lane*16 = dst + i*16 for
+    // i = it*256 + wave*64 + lane; the global source is per lane (apron lanes read a 16-byte zero constant) ---------
     const ST *vimg = value + (long long)b * S * MD + m * D;         // this image, this head
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -278,10 +291,6 @@ __global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
         const int n16 = wsize[l] * QL;
         const ST *vlev = vimg + (long long)St[l] * MD;
         unsigned char *dst = pool + (size_t)wbase[l] * PXB;
-        // LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, so every piece of every level is in flight at
-        // once and the only wait is the barrier below.  The LDS address of a piece is wave-uniform base + lane*16,
-        // which is exactly dst + i*16 for i = wave*64 + lane + it*256; the global source is per lane (apron lanes
-        // read a 16-byte zero constant instead of the map).
         for (int it = 0; it * WIN_BLOCK < n16; ++it) {
           const int i = it * WIN_BLOCK + tid;
           if (i < n16) {
@@ -302,134 +311,198 @@ __global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
     __syncthreads();                                               // (2) windows staged
     stamp(4);
 
-    // ---- gather ------------------------------------------------------------------------------------------------
-    float acc[VEC];
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    // ---- gather, one slot after the other; the next slot's points are in flight meanwhile ----------------------
     const ST *vlane = vimg + c * VEC;                               // + lane's channel slice (global path)
     const unsigned char *pool_lane = pool + c * 16;
-
+    float nx[L][PPL], ny[L][PPL], nw[L][PPL];
+    auto load_points = [&](long long rec, int qi) {
+      const long long r = rec < 0 ? 0 : rec;
+      const float *lrec = loc + r * (L * P * 2) + c * 2;
+      const float *wrec = attn + r * (L * P) + c;
+      const float *rrow = FUSED ? ref + b * ref_batch_stride + (long long)qi * (L * 2) : nullptr;
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-      const int H = Hs[l], W = Ws[l];
-      const bool lds = in_lds[l] != 0;
-      const unsigned row_bytes = (unsigned)(wwid[l] * PXB);
-      // owner side: geometry of my points on this level (corner offsets + bilinear * attention weights)
-      int o1[PPL], o2[PPL], o3[PPL], o4[PPL];
-      float g1[PPL], g2[PPL], g3[PPL], g4[PPL];
+      for (int l = 0; l < L; ++l)
 #pragma unroll
-      for (int k = 0; k < PPL; ++k) {
-        const float h_im = sy[l][k] * H - 0.5f, w_im = sx[l][k] * W - 0.5f;
-        const bool gate = qvalid && h_im > -1 && w_im > -1 && h_im < H && w_im < W;
-        const float hf = floorf(h_im), wf = floorf(w_im);
-        const int y0 = gate ? (int)hf : 0, x0 = gate ? (int)wf : 0;
-        const float lh = gate ? h_im - hf : 0.f, lw = gate ? w_im - wf : 0.f;
-        const float wgt = gate ? sw[l][k] : 0.f;
-        const float hh = 1.f - lh, hw = 1.f - lw;
-        const bool top = gate && y0 >= 0, bot = gate && y0 + 1 <= H - 1;
-        const bool lft = x0 >= 0, rgt = x0 + 1 <= W - 1;
-        const bool ok1 = top && lft, ok2 = top && rgt, ok3 = bot && lft, ok4 = bot && rgt;
-        g1[k] = hh * hw * wgt;
-        g2[k] = hh * lw * wgt;
-        g3[k] = lh * hw * wgt;
-        g4[k] = lh * lw * wgt;
-        if (lds) {
-          // all four corners lie inside the staged window (out-of-map ones are zeros): one offset is enough
-          o1[k] = (wbase[l] + (y0 - wy0[l]) * wwid[l] + (x0 - wx0[l])) * PXB;
-          o2[k] = o3[k] = o4[k] = 0;
-        } else {
-          // element offsets from this image/head base, out-of-map corners -> -1 (load element 0, select 0)
-          const int a = (St[l] + y0 * W + x0) * MD;
-          o1[k] = ok1 ? a : -1;
-          o2[k] = ok2 ? a + MD : -1;
-          o3[k] = ok3 ? a + W * MD : -1;
-          o4[k] = ok4 ? a + W * MD + MD : -1;
-        }
-      }
-
-      // consumer side: every lane walks all P points, taking point p's geometry from its owner lane by DPP
-      auto consume = [&](auto pc, auto lds_c) {
-        constexpr int p = decltype(pc)::value;
-        constexpr bool LDS = decltype(lds_c)::value;
-        constexpr int k = p / QL;
-        constexpr int ctrl = BcastCtrl<QL, p % QL>::value;
-        const int a1 = dpp_i<ctrl>(o1[k]);
-        int a2 = 0, a3 = 0, a4 = 0;
-        const float w1 = dpp_f<ctrl>(g1[k]), w2 = dpp_f<ctrl>(g2[k]);
-        const float w3 = dpp_f<ctrl>(g3[k]), w4 = dpp_f<ctrl>(g4[k]);
-        v16 v1, v2, v3, v4;
-        if constexpr (LDS) {
-          const unsigned char *pa = pool_lane + (unsigned)a1, *pb = pa + row_bytes;
-          v1 = *reinterpret_cast<const v16 *>(pa);
-          v2 = *reinterpret_cast<const v16 *>(pa + PXB);            // immediate ds_read offset
-          v3 = *reinterpret_cast<const v16 *>(pb);
-          v4 = *reinterpret_cast<const v16 *>(pb + PXB);
-        } else {
-          a2 = dpp_i<ctrl>(o2[k]);
-          a3 = dpp_i<ctrl>(o3[k]);
-          a4 = dpp_i<ctrl>(o4[k]);
-          v1 = *reinterpret_cast<const v16 *>(vlane + max(a1, 0));
-          v2 = *reinterpret_cast<const v16 *>(vlane + max(a2, 0));
-          v3 = *reinterpret_cast<const v16 *>(vlane + max(a3, 0));
-          v4 = *reinterpret_cast<const v16 *>(vlane + max(a4, 0));
-        }
-        // explicit 2-wide FMA chains (v_pk_fma_f32): 4 packed FMAs per channel pair, straight into the accumulator
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x2 ww1 = {w1, w1}, ww2 = {w2, w2}, ww3 = {w3, w3}, ww4 = {w4, w4};
-#pragma unroll
-        for (int e = 0; e < VEC; e += 2) {
-          f32x2 x1 = {Traits<T>::to_acc(v1[e]), Traits<T>::to_acc(v1[e + 1])};
-          f32x2 x2 = {Traits<T>::to_acc(v2[e]), Traits<T>::to_acc(v2[e + 1])};
-          f32x2 x3 = {Traits<T>::to_acc(v3[e]), Traits<T>::to_acc(v3[e + 1])};
-          f32x2 x4 = {Traits<T>::to_acc(v4[e]), Traits<T>::to_acc(v4[e + 1])};
-          if constexpr (!LDS) {
-            if (a1 < 0) x1 = f32x2{0.f, 0.f};
-            if (a2 < 0) x2 = f32x2{0.f, 0.f};
-            if (a3 < 0) x3 = f32x2{0.f, 0.f};
-            if (a4 < 0) x4 = f32x2{0.f, 0.f};
+        for (int k = 0; k < PPL; ++k) {
+          const f32x2 xy = *reinterpret_cast<const f32x2 *>(lrec + (l * P + k * QL) * 2);
+          nx[l][k] = xy[0];
+          ny[l][k] = xy[1];
+          nw[l][k] = wrec[l * P + k * QL];
+          if constexpr (FUSED) {
+            const f32x2 rr = *reinterpret_cast<const f32x2 *>(rrow + 2 * l);
+            nx[l][k] = rr[0] + xy[0] / (float)Ws[l];
+            ny[l][k] = rr[1] + xy[1] / (float)Hs[l];
           }
-          f32x2 t = {acc[e], acc[e + 1]};
-          t = __builtin_elementwise_fma(ww1, x1, t);
-          t = __builtin_elementwise_fma(ww2, x2, t);
-          t = __builtin_elementwise_fma(ww3, x3, t);
-          t = __builtin_elementwise_fma(ww4, x4, t);
-          acc[e] = t[0];
-          acc[e + 1] = t[1];
         }
-      };
-      if (lds) {
-        [&]<int... Ps>(std::integer_sequence<int, Ps...>) {
-          (consume(std::integral_constant<int, Ps>{}, std::true_type{}), ...);
-        }(std::make_integer_sequence<int, P>{});
-      } else {
-        [&]<int... Ps>(std::integer_sequence<int, Ps...>) {
-          (consume(std::integral_constant<int, Ps>{}, std::false_type{}), ...);
-        }(std::make_integer_sequence<int, P>{});
+      if constexpr (FUSED) {   // softmax over the record's L*P logits: my points + DPP across the QL lanes
+        float mx = -INFINITY;
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+          for (int k = 0; k < PPL; ++k) mx = fmaxf(mx, nw[l][k]);
+        mx = fmaxf(mx, dpp_f<0xB1>(mx));
+        if constexpr (QL == 4) mx = fmaxf(mx, dpp_f<0x4E>(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+          for (int k = 0; k < PPL; ++k) {
+            nw[l][k] = expf(nw[l][k] - mx);
+            sum += nw[l][k];
+          }
+        sum += dpp_f<0xB1>(sum);
+        if constexpr (QL == 4) sum += dpp_f<0x4E>(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+          for (int k = 0; k < PPL; ++k) nw[l][k] *= inv;
+      }
+    };
+    load_points(recs[0], qidx[0]);
+
+#pragma unroll 1
+    for (int s = 0; s < NS; ++s) {
+      long long rec = recs[0];
+#pragma unroll
+      for (int u = 1; u < NS; ++u) rec = s == u ? recs[u] : rec;
+      long long rec_next = -1;
+      int q_next = 0;
+#pragma unroll
+      for (int u = 1; u < NS; ++u) {
+        rec_next = s + 1 == u ? recs[u] : rec_next;
+        q_next = s + 1 == u ? qidx[u] : q_next;
+      }
+      const bool qvalid = rec >= 0;
+      float sx[L][PPL], sy[L][PPL], sw[L][PPL];
+#pragma unroll
+      for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) {
+          sx[l][k] = nx[l][k];
+          sy[l][k] = ny[l][k];
+          sw[l][k] = nw[l][k];
+        }
+      if (s + 1 < NS) load_points(rec_next, q_next);
+
+      f32x2 accp[4][VEC / 2];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int e = 0; e < VEC / 2; ++e) accp[a][e] = f32x2{0.f, 0.f};
+
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const int H = Hs[l], W = Ws[l];
+        const bool lds = in_lds[l] != 0;
+        const unsigned row_bytes = (unsigned)(wwid[l] * PXB);
+        // owner side: geometry of my points on this level (corner offsets + bilinear * attention weights)
+        int o1[PPL], o2[PPL], o3[PPL], o4[PPL];
+        float g1[PPL], g2[PPL], g3[PPL], g4[PPL];
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) {
+          const float h_im = sy[l][k] * H - 0.5f, w_im = sx[l][k] * W - 0.5f;
+          const bool gate = qvalid && h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+          const float hf = floorf(h_im), wf = floorf(w_im);
+          const int y0 = gate ? (int)hf : 0, x0 = gate ? (int)wf : 0;
+          const float lh = gate ? h_im - hf : 0.f, lw = gate ? w_im - wf : 0.f;   // gated-out: weight 0 (cuh:290-296)
+          const float wgt = gate ? sw[l][k] : 0.f;
+          const float hh = 1.f - lh, hw = 1.f - lw;
+          g1[k] = hh * hw * wgt;
+          g2[k] = hh * lw * wgt;
+          g3[k] = lh * hw * wgt;
+          g4[k] = lh * lw * wgt;
+          if (lds) {
+            // all four corners lie inside the staged window (out-of-map ones are zeros): one offset is enough
+            // (a gated-out sample reads the two zero pixels: offset 0, row step 0)
+            o1[k] = gate ? (wbase[l] + __mul24(y0 - wy0[l], wwid[l]) + (x0 - wx0[l])) * PXB : 0;
+            o2[k] = gate ? (int)row_bytes : 0;
+            o3[k] = o4[k] = 0;
+          } else {
+            // element offsets from this image/head base, out-of-map corners -> -1 (load element 0, select 0)
+            const bool top = gate && y0 >= 0, bot = gate && y0 + 1 <= H - 1;
+            const bool lft = x0 >= 0, rgt = x0 + 1 <= W - 1;
+            const int a = (St[l] + y0 * W + x0) * MD;
+            o1[k] = (top && lft) ? a : -1;
+            o2[k] = (top && rgt) ? a + MD : -1;
+            o3[k] = (bot && lft) ? a + W * MD : -1;
+            o4[k] = (bot && rgt) ? a + W * MD + MD : -1;
+          }
+        }
+
+        // consumer side: every lane walks all P points, taking point p's geometry from its owner lane by DPP
+        auto consume = [&](auto pc, auto lds_c) {
+          constexpr int p = decltype(pc)::value;
+          constexpr bool LDS = decltype(lds_c)::value;
+          constexpr int k = p / QL;
+          constexpr int ctrl = BcastCtrl<QL, p % QL>::value;
+          const int a1 = dpp_i<ctrl>(o1[k]);
+          int a2 = 0, a3 = 0, a4 = 0;
+          const float w1 = dpp_f<ctrl>(g1[k]), w2 = dpp_f<ctrl>(g2[k]);
+          const float w3 = dpp_f<ctrl>(g3[k]), w4 = dpp_f<ctrl>(g4[k]);
+          v16 v1, v2, v3, v4;
+          if constexpr (LDS) {
+            const unsigned char *pa = pool_lane + (unsigned)a1, *pb = pa + (unsigned)dpp_i<ctrl>(o2[k]);
+            v1 = *reinterpret_cast<const v16 *>(pa);
+            v2 = *reinterpret_cast<const v16 *>(pa + PXB);          // immediate ds_read offset
+            v3 = *reinterpret_cast<const v16 *>(pb);
+            v4 = *reinterpret_cast<const v16 *>(pb + PXB);
+          } else {
+            a2 = dpp_i<ctrl>(o2[k]);
+            a3 = dpp_i<ctrl>(o3[k]);
+            a4 = dpp_i<ctrl>(o4[k]);
+            v1 = *reinterpret_cast<const v16 *>(vlane + max(a1, 0));
+            v2 = *reinterpret_cast<const v16 *>(vlane + max(a2, 0));
+            v3 = *reinterpret_cast<const v16 *>(vlane + max(a3, 0));
+            v4 = *reinterpret_cast<const v16 *>(vlane + max(a4, 0));
+          }
+          // explicit 2-wide FMA chains (v_pk_fma_f32): 4 packed FMAs per channel pair into the accumulator
+          const f32x2 ww1 = {w1, w1}, ww2 = {w2, w2}, ww3 = {w3, w3}, ww4 = {w4, w4};
+#pragma unroll
+          for (int e = 0; e < VEC; e += 2) {
+            f32x2 x1 = {Traits<T>::to_acc(v1[e]), Traits<T>::to_acc(v1[e + 1])};
+            f32x2 x2 = {Traits<T>::to_acc(v2[e]), Traits<T>::to_acc(v2[e + 1])};
+            f32x2 x3 = {Traits<T>::to_acc(v3[e]), Traits<T>::to_acc(v3[e + 1])};
+            f32x2 x4 = {Traits<T>::to_acc(v4[e]), Traits<T>::to_acc(v4[e + 1])};
+            if constexpr (!LDS) {
+              if (a1 < 0) x1 = f32x2{0.f, 0.f};
+              if (a2 < 0) x2 = f32x2{0.f, 0.f};
+              if (a3 < 0) x3 = f32x2{0.f, 0.f};
+              if (a4 < 0) x4 = f32x2{0.f, 0.f};
+            }
+            // one accumulator per corner: 4 independent FMA chains per channel pair, so consecutive packed FMAs never
+            // wait on each other (a single chain stalls the wave on every FMA's latency at 3-4 waves per SIMD)
+            accp[0][e / 2] = __builtin_elementwise_fma(ww1, x1, accp[0][e / 2]);
+            accp[1][e / 2] = __builtin_elementwise_fma(ww2, x2, accp[1][e / 2]);
+            accp[2][e / 2] = __builtin_elementwise_fma(ww3, x3, accp[2][e / 2]);
+            accp[3][e / 2] = __builtin_elementwise_fma(ww4, x4, accp[3][e / 2]);
+          }
+        };
+        if (lds) {
+          [&]<int... Ps>(std::integer_sequence<int, Ps...>) {
+            (consume(std::integral_constant<int, Ps>{}, std::true_type{}), ...);
+          }(std::make_integer_sequence<int, P>{});
+        } else {
+          [&]<int... Ps>(std::integer_sequence<int, Ps...>) {
+            (consume(std::integral_constant<int, Ps>{}, std::false_type{}), ...);
+          }(std::make_integer_sequence<int, P>{});
+        }
+      }
+
+      if (qvalid) {
+        v16 o;
+#pragma unroll
+        for (int e = 0; e < VEC / 2; ++e) {
+          const f32x2 t = (accp[0][e] + accp[1][e]) + (accp[2][e] + accp[3][e]);
+          o[2 * e] = Traits<T>::from_acc(t[0]);
+          o[2 * e + 1] = Traits<T>::from_acc(t[1]);
+        }
+        *reinterpret_cast<v16 *>(out + rec * D + c * VEC) = o;
       }
     }
-
     stamp(5);
-    if (qvalid) {
-      v16 o;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) o[e] = Traits<T>::from_acc(acc[e]);
-      *reinterpret_cast<v16 *>(out + rec * D + c * VEC) = o;
-    }
     __syncthreads();                                               // (3) pool / bb free for the next item
     stamp(6);
-
-    // rotate the prefetched item in
-    rec = nrec;
-    b = nb;
-    m = nm;
-#pragma unroll
-    for (int l = 0; l < L; ++l)
-#pragma unroll
-      for (int k = 0; k < PPL; ++k) {
-        sx[l][k] = nx[l][k];
-        sy[l][k] = ny[l][k];
-        sw[l][k] = nw[l][k];
-      }
   }
   if constexpr (STAMP) {
     if (tid == 0 && stamps)
@@ -440,52 +513,68 @@ __global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
 static unsigned long long *g_stamp_buffer = nullptr;
 void set_win_stamp_buffer(void *p) { g_stamp_buffer = static_cast<unsigned long long *>(p); }
 
-// ---- launcher: returns -100 when this geometry is not covered (caller uses the generic kernel) -----------------
+// ---- launcher: returns -100 when this geometry is not covered (caller uses another kernel) ----------------------
+// ref == nullptr: plain op; ref != nullptr: fused front-end (loc = raw offsets, attn = raw logits).
 template <typename T>
 int launch_msda_forward_win(const void *value, const int64_t *shapes, const int64_t *starts, const void *loc,
                             const void *attn, int N, int S, int M, int D, int L, int Lq, int P, void *out,
-                            hipStream_t stream)
+                            hipStream_t stream, const float *ref, long long ref_batch_stride)
 {
   using ST = typename Traits<T>::store_t;
   constexpr int VEC = 16 / (int)sizeof(ST);
   if ((((uintptr_t)value | (uintptr_t)out) & 15u) || (((uintptr_t)loc) & 7u) || (((uintptr_t)attn) & 3u)) return -100;
-  if (D != 16 || !((P == 4 && L >= 3 && L <= 5) || (P == 8 && L == 5))) return -100;
+  if (ref && (((uintptr_t)ref) & 7u)) return -100;
+  if (D != 16 || P != 4 || L < 3 || L > 5) return -100;
   if ((long long)N * Lq * M < 32768) return -100;                  // too small to fill a persistent grid
   if ((long long)N * ((long long)S + 64 * L) * M >= 0x7fffffffLL) return -100;   // item counter is 32-bit
   constexpr int QL = 16 / VEC;
-  const int pool_px = QL == 4 ? 448 : 896;                          // 28 KB of head-pixels
-  const size_t lds = (size_t)(pool_px + 1) * QL * 16 + (WIN_BLOCK / 64) * WIN_MAXL * 2 * sizeof(unsigned);
+  static const int ns_env = [] { const char *e = getenv("PCT_WIN_NS"); return e ? atoi(e) : 4; }();
+  const int NS = (ns_env == 1 || ns_env == 2) ? ns_env : 4;
+  const int pool_bytes = NS == 1 ? 28 * 1024 : (NS == 2 ? 36 * 1024 : 50 * 1024);
+  const int pool_px = pool_bytes / (QL * 16);
+  const size_t lds = (size_t)pool_px * QL * 16 + (WIN_BLOCK / 64) * WIN_MAXL * 2 * sizeof(unsigned);
   const int pyramid = Lq == S ? 1 : 0;
-  const dim3 grid(256 * 4), block(WIN_BLOCK);
+  const int wg_per_cu = NS == 4 ? 3 : 4;
+  const dim3 grid(256 * wg_per_cu), block(WIN_BLOCK);
   const ST *v = static_cast<const ST *>(value);
   const float *lc = static_cast<const float *>(loc), *at = static_cast<const float *>(attn);
   ST *o = static_cast<ST *>(out);
-#define PCT_WIN(L_, P_)                                                                                          \
-  hipLaunchKernelGGL((msda_forward_win_kernel<T, 16, L_, P_>), grid, block, lds, stream, v, shapes, starts, lc, at, \
-                     N, S, M, Lq, pyramid, pool_px, o)
   if constexpr (sizeof(ST) == 4) {
-    if (g_stamp_buffer && P == 4 && L == 4) {   // diagnostic build: per-phase cycle stamps (tools/stamp_msda.py)
-      hipLaunchKernelGGL((msda_forward_win_kernel<T, 16, 4, 4, true>), grid, block, lds, stream, v, shapes, starts, lc,
-                         at, N, S, M, Lq, pyramid, pool_px, o, g_stamp_buffer);
+    if (g_stamp_buffer && !ref && L == 4 && NS == 2) {   // diagnostic build: per-phase cycle stamps (tools/stamp_msda.py)
+      hipLaunchKernelGGL((msda_forward_win_kernel<T, 16, 4, 4, 2, false, true>), grid, block, lds, stream, v, shapes,
+                         starts, lc, at, N, S, M, Lq, pyramid, pool_px, o, ref, ref_batch_stride, g_stamp_buffer);
       return (int)hipGetLastError();
     }
   }
-  if (P == 4 && L == 3) PCT_WIN(3, 4);
-  else if (P == 4 && L == 4) PCT_WIN(4, 4);
-  else if (P == 4 && L == 5) PCT_WIN(5, 4);
-  else if (P == 8 && L == 5) PCT_WIN(5, 8);
-  else return -100;
+#define PCT_WIN(L_, NS_, FU_)                                                                                      \
+  hipLaunchKernelGGL((msda_forward_win_kernel<T, 16, L_, 4, NS_, FU_>), grid, block, lds, stream, v, shapes, starts, \
+                     lc, at, N, S, M, Lq, pyramid, pool_px, o, ref, ref_batch_stride, nullptr)
+#define PCT_WIN_L(NS_, FU_)                 \
+  if (L == 3) PCT_WIN(3, NS_, FU_);         \
+  else if (L == 4) PCT_WIN(4, NS_, FU_);    \
+  else PCT_WIN(5, NS_, FU_)
+  if (ref) {
+    if (NS == 4) { PCT_WIN_L(4, true); }
+    else if (NS == 2) { PCT_WIN_L(2, true); }
+    else { PCT_WIN_L(1, true); }
+  } else {
+    if (NS == 4) { PCT_WIN_L(4, false); }
+    else if (NS == 2) { PCT_WIN_L(2, false); }
+    else { PCT_WIN_L(1, false); }
+  }
+#undef PCT_WIN_L
 #undef PCT_WIN
   return (int)hipGetLastError();
 }
 
 template int launch_msda_forward_win<float>(const void *, const int64_t *, const int64_t *, const void *,
-                                            const void *, int, int, int, int, int, int, int, void *, hipStream_t);
+                                            const void *, int, int, int, int, int, int, int, void *, hipStream_t,
+                                            const float *, long long);
 template int launch_msda_forward_win<half_bits>(const void *, const int64_t *, const int64_t *, const void *,
-                                                const void *, int, int, int, int, int, int, int, void *,
-                                                hipStream_t);
+                                                const void *, int, int, int, int, int, int, int, void *, hipStream_t,
+                                                const float *, long long);
 template int launch_msda_forward_win<bf16_bits>(const void *, const int64_t *, const int64_t *, const void *,
-                                                const void *, int, int, int, int, int, int, int, void *,
-                                                hipStream_t);
+                                                const void *, int, int, int, int, int, int, int, void *, hipStream_t,
+                                                const float *, long long);
 
 }  // namespace pct
