@@ -1,0 +1,70 @@
+"""Point-sampled Hungarian matcher.
+
+Mirrors loss/matcher.py:70-222 of the reference (`Point_HungarianMatcher`, `batch_dice_loss`, `batch_sigmoid_ce_loss`):
+per image, `num_points` random points are sampled from predicted and target masks, the [Q, G] cost
+cost_mask * BCE + cost_dice * dice is formed with two GEMMs on the device, and scipy's linear_sum_assignment solves it.
+Same RNG consumption (one torch.rand(1, num_points, 2) per image) so seeded runs match.  The reference's
+`torch.cuda.empty_cache()` after every image (matcher.py:160) is dropped: it only stalls the allocator.
+"""
+import torch
+import torch.nn.functional as F
+from scipy.optimize import linear_sum_assignment
+from torch import nn
+
+from .point_features import point_sample
+
+
+def batch_dice_loss(inputs: torch.Tensor, targets: torch.Tensor):
+    inputs = inputs.sigmoid().flatten(1)
+    numerator = 2 * torch.einsum("nc,mc->nm", inputs, targets)
+    denominator = inputs.sum(-1)[:, None] + targets.sum(-1)[None, :]
+    return 1 - (numerator + 1) / (denominator + 1)
+
+
+def batch_sigmoid_ce_loss(inputs: torch.Tensor, targets: torch.Tensor):
+    hw = inputs.shape[1]
+    pos = F.binary_cross_entropy_with_logits(inputs, torch.ones_like(inputs), reduction="none")
+    neg = F.binary_cross_entropy_with_logits(inputs, torch.zeros_like(inputs), reduction="none")
+    loss = torch.einsum("nc,mc->nm", pos, targets) + torch.einsum("nc,mc->nm", neg, (1 - targets))
+    return loss / hw
+
+
+class Point_HungarianMatcher(nn.Module):
+    def __init__(self, cost_mask: float = 1, cost_dice: float = 1, num_points: int = 0):
+        super().__init__()
+        self.cost_mask = cost_mask
+        self.cost_dice = cost_dice
+        assert cost_mask != 0 or cost_dice != 0, "all costs cant be 0"
+        self.num_points = num_points
+
+    @torch.no_grad()
+    def memory_efficient_forward(self, outputs, targets):
+        bs, num_queries = outputs["pred_masks"].shape[:2]
+        costs = []
+        for b in range(bs):
+            out_mask = outputs["pred_masks"][b][:, None]                      # [Q, 1, H, W]
+            tgt_mask = targets[b]["masks"].to(out_mask)[:, None]              # [G, 1, Ht, Wt]
+            point_coords = torch.rand(1, self.num_points, 2, device=out_mask.device)
+            tgt_pts = point_sample(tgt_mask, point_coords.repeat(tgt_mask.shape[0], 1, 1),
+                                   align_corners=False).squeeze(1)
+            out_pts = point_sample(out_mask, point_coords.repeat(out_mask.shape[0], 1, 1),
+                                   align_corners=False).squeeze(1)
+            with torch.autocast(device_type=out_mask.device.type, enabled=False):
+                out_pts, tgt_pts = out_pts.float(), tgt_pts.float()
+                C = self.cost_mask * batch_sigmoid_ce_loss(out_pts, tgt_pts) \
+                    + self.cost_dice * batch_dice_loss(out_pts, tgt_pts)
+            costs.append(C.reshape(num_queries, -1))
+        # one device -> host transfer per call instead of one per image
+        indices = [linear_sum_assignment(C.cpu()) for C in costs]
+        return [(torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)) for i, j in indices]
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        """outputs["pred_masks"] [B, Q, H, W]; targets: list of dicts with "masks" [G_b, Ht, Wt].
+        -> list of (pred_idx, tgt_idx) int64 tensors, len = min(Q, G_b)."""
+        return self.memory_efficient_forward(outputs, targets)
+
+    def __repr__(self, _repr_indent=4):
+        head = "Matcher " + self.__class__.__name__
+        body = ["cost_mask: {}".format(self.cost_mask), "cost_dice: {}".format(self.cost_dice)]
+        return "\n".join([head] + [" " * _repr_indent + line for line in body])

@@ -64,3 +64,39 @@ def test_head_bf16_autocast_fused_runs_and_is_close_to_fp32():
     a, b = pred16["pred_masks"].float(), pred32["pred_masks"]
     scale = max(1.0, float(b.abs().max()))
     assert float(((a - b).abs() <= 0.1 * scale).float().mean()) > 0.9
+
+
+def test_maskformer_train_step_and_eval_on_gpu():
+    """Whole meta-arch on the device: train step (matcher, criterion, query contrast, HIP MSDeformAttn forward +
+    backward kernels under autograd) and eval with instance post-processing."""
+    import random
+    from pctrans_amd.arch import maskformer as mfm
+    from pctrans_amd.arch.resnet import ResNet
+    from pctrans_amd.config import get_cfg
+    from test_arch_cpu import _blob
+    random.seed(0)
+    torch.manual_seed(0)
+    cfg = get_cfg(num_queries=12, norm="BN", sem_norm="BN", enc_layers=2, dec_layers=3, train_num_points=512,
+                  dataset="BBBC")
+    model = mfm.MaskFormer(**mfm.MaskFormer.from_config(cfg, ResNet(18, 3, norm="BN"))).cuda()
+    H = W = 128
+    vol = torch.randn(2, 3, H, W, device="cuda")
+    targets = []
+    for b in range(2):
+        masks = torch.stack([_blob(H, W, 30, 30, 14), _blob(H, W, 90, 80, 20), _blob(H, W, 40, 100, 10)]).cuda()
+        centers = torch.tensor([[30 / W, 30 / H], [80 / W, 90 / H], [100 / W, 40 / H]], device="cuda").view(3, 1, 2)
+        targets.append({"masks": masks, "labels": torch.ones(3, dtype=torch.long, device="cuda"),
+                        "fg_masks": (masks.sum(0) > 0).float(), "center_points": centers})
+    model.train()
+    losses = model(vol, targets, True)
+    total = sum(v for v in losses.values() if torch.is_tensor(v))
+    assert torch.isfinite(total)
+    total.backward()
+    sa = model.sem_seg_head.pixel_decoder.transformer.encoder.layers[0].self_attn
+    for p in (sa.value_proj.weight, sa.sampling_offsets.weight, sa.attention_weights.weight):
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    assert float(sa.sampling_offsets.weight.grad.abs().sum()) > 0      # grad_sampling_loc from the HIP backward
+    model.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out, _ = model(vol)
+    assert out.shape == (2, H, W) and out.dtype == torch.int16
