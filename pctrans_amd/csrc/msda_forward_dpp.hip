@@ -103,7 +103,7 @@ __global__ __launch_bounds__(1024) void msda_forward_dpp_kernel(
     float sum = 0.f;
     for (int l = 0; l < L; ++l)
 #pragma unroll
-      for (int k = 0; k < PPL; ++k) sum += expf(wrec[l * P + k * QL] - mx);
+      for (int k = 0; k < PPL; ++k) sum += __expf(wrec[l * P + k * QL] - mx);
     sum += qbcast_f<0xB1>(sum);
     if constexpr (QL == 4) sum += qbcast_f<0x4E>(sum);
     sm_max = mx;
@@ -147,12 +147,12 @@ __global__ __launch_bounds__(1024) void msda_forward_dpp_kernel(
     const unsigned lvl = (unsigned)starts[l] * MDb;
     if constexpr (FUSED) {
       const float rx = rrec[2 * l], ry = rrec[2 * l + 1];
-      const float fw = (float)W, fh = (float)H;
+      const float iw = 1.0f / (float)W, ih = 1.0f / (float)H;      // uniform: one reciprocal per level
 #pragma unroll
       for (int k = 0; k < PPL; ++k) {
-        cx[k] = rx + cx[k] / fw;                                    // reference_points + offsets / (W_l, H_l)
-        cy[k] = ry + cy[k] / fh;
-        cw[k] = expf(cw[k] - sm_max) * sm_inv;                      // softmax weight
+        cx[k] = fmaf(cx[k], iw, rx);                                // reference_points + offsets / (W_l, H_l)
+        cy[k] = fmaf(cy[k], ih, ry);
+        cw[k] = __expf(cw[k] - sm_max) * sm_inv;                    // softmax weight
       }
     }
 

@@ -113,7 +113,7 @@ __device__ __forceinline__ LevelWindow read_window(const unsigned *bb, const int
 // location = ref[q, l] + offset / (W_l, H_l) and weight = softmax over the record's L*P logits itself
 // (ops/modules/ms_deform_attn.py:100-109), as msda_forward_dpp.hip does.
 template <typename T, int D, int L, int P, int NS, bool FUSED, bool STAMP = false>
-__global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
+__global__ __launch_bounds__(WIN_BLOCK, NS == 4 ? 3 : 4) void msda_forward_win_kernel(   // NS=4: 50 KB LDS -> 3 WG/CU
     const typename Traits<T>::store_t *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn, const int N,
     const int S, const int M, const int Lq, const int pyramid, const int pool_px,
@@ -165,6 +165,14 @@ __global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
     Ws[l] = (int)shapes[2 * l + 1];
     St[l] = (int)starts[l];
     tiles_before[l + 1] = tiles_before[l] + ((Hs[l] + THT - 1) / THT) * ((Ws[l] + TW - 1) / TW);
+  }
+  // FUSED: offsets are divided by (W_l, H_l); the quotient is formed as offset * (1 / W_l) with the reciprocal
+  // computed once per level (<= 1 ulp from the true quotient of the reference, i.e. < 1e-6 pixel)
+  float invW[L], invH[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    invW[l] = 1.0f / (float)Ws[l];
+    invH[l] = 1.0f / (float)Hs[l];
   }
   const int T_img = pyramid ? tiles_before[L] : (Lq + TQ * NS - 1) / (TQ * NS);
   const int items = N * T_img * M;
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
             f32x2 v = *reinterpret_cast<const f32x2 *>(lrec + (l * P + k * QL) * 2);
             if constexpr (FUSED) {
               const f32x2 r = *reinterpret_cast<const f32x2 *>(rrow + 2 * l);
-              v = f32x2{r[0] + v[0] / (float)Ws[l], r[1] + v[1] / (float)Hs[l]};
+              v = f32x2{fmaf(v[0], invW[l], r[0]), fmaf(v[1], invH[l], r[1])};
             }
             pxy[s][l][k] = v;
           }
@@ -330,8 +338,8 @@ __global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
           nw[l][k] = wrec[l * P + k * QL];
           if constexpr (FUSED) {
             const f32x2 rr = *reinterpret_cast<const f32x2 *>(rrow + 2 * l);
-            nx[l][k] = rr[0] + xy[0] / (float)Ws[l];
-            ny[l][k] = rr[1] + xy[1] / (float)Hs[l];
+            nx[l][k] = fmaf(xy[0], invW[l], rr[0]);
+            ny[l][k] = fmaf(xy[1], invH[l], rr[1]);
           }
         }
       if constexpr (FUSED) {   // softmax over the record's L*P logits: my points + DPP across the QL lanes
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(WIN_BLOCK, 4) void msda_forward_win_kernel(
         for (int l = 0; l < L; ++l)
 #pragma unroll
           for (int k = 0; k < PPL; ++k) {
-            nw[l][k] = expf(nw[l][k] - mx);
+            nw[l][k] = __expf(nw[l][k] - mx);
             sum += nw[l][k];
           }
         sum += dpp_f<0xB1>(sum);
