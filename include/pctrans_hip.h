@@ -123,6 +123,17 @@ PCT_API int pct_dynamic_mask_head_forward(const float *mask_feat, const float *r
                                           int rel_coord, int target_h, int target_w, int out_dtype, void *up_logits,
                                           unsigned char *attn_mask, void *stream);
 
+/* ---- dynamic mask head, bf16-autocast configuration, on MFMA ----------------------------------------------
+ * Same contract as pct_dynamic_mask_head_forward with out_dtype = 2 (bfloat16 outputs), computed as two launches:
+ * the per-query 3-layer MLP on v_mfma_f32_16x16x16_bf16 (features / generated weights / hidden activations in bf16,
+ * fp32 accumulation, relative-coordinate inputs and biases in fp32) and a streaming x2-upsample + attention-mask pass.
+ * `scratch` is a caller-owned workspace of batch*num_query*height*width bfloat16 elements (the logits at feature
+ * resolution); nothing is allocated inside the call. */
+PCT_API int pct_dynamic_mask_head_forward_mfma(const float *mask_feat, const float *ref_points, const float *params,
+                                               int batch, int channels, int num_query, int height, int width,
+                                               int stride, int rel_coord, int target_h, int target_w, void *scratch,
+                                               void *up_logits, unsigned char *attn_mask, void *stream);
+
 /* ---- fused residual add + LayerNorm:  out = LayerNorm(x + y) * gamma + beta  over the last dimension ----------
  * Replaces the `x + dropout(y)` / `nn.LayerNorm` pairs of the encoder and decoder layers in eval mode
  * (pixel_decoder/msdeformattn.py:116-131; transformer_decoder/mask2former_transformer_decoder.py:97-99, 179-181,

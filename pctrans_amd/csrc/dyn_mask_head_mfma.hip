@@ -1,0 +1,258 @@
+// Per-query dynamic mask head on CDNA4 MFMA (gfx950, wave64) for the bf16-autocast configuration, in two kernels:
+//
+//   A  dmh_logits_mfma_kernel : the 3-layer per-query MLP  (mask2former_transformer_decoder.py:699-719)
+//        x0 = relu(W0[q] . [rel_x, rel_y, feat] + b0[q]),  x1 = relu(W1[q] . x0 + b1[q]),  logit = W2[q] . x1 + b2[q]
+//      as chained v_mfma_f32_16x16x16_bf16.  One MFMA tile = 2 queries x 8 hidden rows (M = 16) by 16 pixels (N = 16);
+//      layer 0 contracts over the 16 feature channels (K = 16 exactly), layer 1 over the 16 hidden rows of the query
+//      pair with a block-diagonal W1.  The accumulator layout of layer 0 (lane (g, px) holds rows 4g..4g+3) IS the
+//      B-operand layout of a K = 16 MFMA (lane (g, px) supplies k = 4g..4g+3), so x0 goes from accumulator registers to
+//      operand registers with a relu and a bf16 pack -- no LDS, no shuffles.  The two relative-coordinate inputs and
+//      the biases enter as the fp32 initial accumulator (more accurate than the reference's bf16 conv inputs), layer 2
+//      (8 MACs) is a 4-FMA partial dot per lane plus one cross-group add.  Feature fragments of a wave's 8 pixel tiles
+//      stay in registers across all query pairs; per-pair weights are fetched once per pair.
+//   B  dmh_resize_kernel : bilinear x2 upsample (align_corners = False) of the bf16 logit planes + the boolean
+//      attention mask  sigmoid(resize to (th, tw)) < 0.5   (:689-695), a pure streaming pass through an LDS row band.
+//
+// Under autocast the reference's convolutions take bf16 inputs/weights with fp32 accumulation and emit bf16; here the
+// hidden activations are likewise rounded to bf16 between layers 0 and 1 and the logits are stored as bf16.
+#include "msda_common.hpp"
+
+namespace pct {
+
+typedef __bf16 dm_bf16x4 __attribute__((ext_vector_type(4)));
+typedef short dm_s16x4 __attribute__((ext_vector_type(4)));
+typedef float dm_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DMM_PT = 8;        // pixel tiles (16 px each) per wave
+constexpr int DMM_BLOCK = 256;
+
+__device__ __forceinline__ dm_s16x4 pack_bf16x4(float a, float b, float c, float d)
+{
+  const dm_bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+  return __builtin_bit_cast(dm_s16x4, v);
+}
+
+// feat [N, 16, H, W] fp32, ref [N, Q, 2], params [N, Q, G] fp32 (G = 233 with rel coords, 217 without),
+// logits [N, Q, H*W] bf16
+template <bool REL>
+__global__ __launch_bounds__(DMM_BLOCK) void dmh_logits_mfma_kernel(const float *__restrict__ feat,
+                                                                    const float *__restrict__ ref,
+                                                                    const float *__restrict__ params, const int Q,
+                                                                    const int H, const int W, const int stride,
+                                                                    const int blocks_per_image,
+                                                                    __bf16 *__restrict__ logits)
+{
+  constexpr int C = 16, HID = 8, CIN = REL ? C + 2 : C;
+  constexpr int G = CIN * HID + HID * HID + HID + HID + HID + 1;
+  constexpr int OFF_W1 = CIN * HID, OFF_W2 = OFF_W1 + HID * HID, OFF_B0 = OFF_W2 + HID;
+  constexpr int OFF_B1 = OFF_B0 + HID, OFF_B2 = OFF_B1 + HID;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, g = lane >> 4;                    // MFMA column (pixel / weight row) and lane group
+  const int HW = H * W;
+  const int n = blockIdx.x / blocks_per_image;
+  const int pb = blockIdx.x - n * blocks_per_image;
+  const int px_base = (pb * (DMM_BLOCK / 64) + wave) * (DMM_PT * 16);
+
+  // ---- B operand of layer 0: feat[ch = 4g + j][px] for my pixel column of each tile (kept for all query pairs) ----
+  dm_s16x4 fb[DMM_PT];
+  float lx[DMM_PT], ly[DMM_PT];
+  const float *fimg = feat + (size_t)n * C * HW;
+  const float half = (float)(stride / 2);
+#pragma unroll
+  for (int t = 0; t < DMM_PT; ++t) {
+    const int px = min(px_base + t * 16 + col, HW - 1);
+    const float *fp = fimg + (size_t)(4 * g) * HW + px;
+    fb[t] = pack_bf16x4(fp[0], fp[(size_t)HW], fp[(size_t)2 * HW], fp[(size_t)3 * HW]);
+    const int y = px / W, x = px - y * W;
+    lx[t] = (float)(x * stride) + half;
+    ly[t] = (float)(y * stride) + half;
+  }
+
+  const int npairs = (Q + 1) / 2;
+  for (int pr = 0; pr < npairs; ++pr) {
+    // the query this lane's accumulator rows (4g .. 4g+3) belong to, and the query of my A-operand row `col`
+    const int q_acc = min(2 * pr + (g >> 1), Q - 1);
+    const int q_row = min(2 * pr + (col >> 3), Q - 1);
+    const float *pa = params + ((size_t)n * Q + q_acc) * G;      // for accumulator-side constants
+    const float *prw = params + ((size_t)n * Q + q_row) * G;     // for A-operand rows
+    const int hr = col & 7;                                      // hidden row of A-operand row `col`
+    const int r0 = (4 * g) & 7;                                  // first hidden row of my accumulator rows
+
+    // A operand, layer 0: W0feat[q_row][hr][ch = 4g + j]
+    const float *w0r = prw + hr * CIN + (REL ? 2 : 0) + 4 * g;
+    const dm_s16x4 a0 = pack_bf16x4(w0r[0], w0r[1], w0r[2], w0r[3]);
+    // A operand, layer 1: block-diagonal W1: row `col` (query col>>3, hidden hr) x k = 4g + j (query g>>1, hidden (4g+j)&7)
+    dm_s16x4 a1 = {0, 0, 0, 0};
+    if ((col >> 3) == (g >> 1)) {
+      const float *w1r = prw + OFF_W1 + hr * HID + ((4 * g) & 7);
+      a1 = pack_bf16x4(w1r[0], w1r[1], w1r[2], w1r[3]);
+    }
+    // accumulator-side constants of rows 4g .. 4g+3 (all of query q_acc)
+    float b0v[4], b1v[4], w2v[4], wxv[4], wyv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      b0v[r] = pa[OFF_B0 + r0 + r];
+      b1v[r] = pa[OFF_B1 + r0 + r];
+      w2v[r] = pa[OFF_W2 + r0 + r];
+      wxv[r] = REL ? pa[(r0 + r) * CIN + 0] : 0.f;
+      wyv[r] = REL ? pa[(r0 + r) * CIN + 1] : 0.f;
+    }
+    const float b2 = pa[OFF_B2];
+    float rx = 0.f, ry = 0.f;
+    if constexpr (REL) {
+      rx = ref[((size_t)n * Q + q_acc) * 2] * (float)(W * stride);
+      ry = ref[((size_t)n * Q + q_acc) * 2 + 1] * (float)(H * stride);
+    }
+    __bf16 *lrow = logits + ((size_t)n * Q + q_acc) * HW;
+    const bool writer = (g & 1) == 0 && 2 * pr + (g >> 1) < Q;   // groups 0 / 2 hold the reduced logit of q0 / q1
+
+#pragma unroll
+    for (int t = 0; t < DMM_PT; ++t) {
+      const float relx = rx - lx[t], rely = ry - ly[t];
+      dm_f32x4 c0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c0[r] = fmaf(wyv[r], rely, fmaf(wxv[r], relx, b0v[r]));
+      c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, fb[t], c0, 0, 0, 0);
+      // relu + bf16: accumulator rows 4g..4g+3 of pixel `col` == B operand k-slots 4g..4g+3 of column `col`
+      const dm_s16x4 xb = pack_bf16x4(fmaxf(c0[0], 0.f), fmaxf(c0[1], 0.f), fmaxf(c0[2], 0.f), fmaxf(c0[3], 0.f));
+      dm_f32x4 c1 = {b1v[0], b1v[1], b1v[2], b1v[3]};
+      c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, xb, c1, 0, 0, 0);
+      float part = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part = fmaf(w2v[r], fmaxf(c1[r], 0.f), part);
+      part += __shfl_xor(part, 16);                              // rows 4g..4g+3 (+) rows of the partner group
+      const int px = px_base + t * 16 + col;
+      if (writer && px < HW) lrow[px] = (__bf16)(part + b2);
+    }
+  }
+}
+
+// PyTorch upsample_bilinear2d source index (align_corners = False)
+__device__ __forceinline__ void dm_bilinear_src(int dst, float scale, int in_size, int &i0, int &i1, float &lam)
+{
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  lam = src - (float)i0;
+}
+
+// logits [N*Q, H, W] bf16 -> up [N*Q, 2H, 2W] bf16, amask [N*Q, th*tw] bytes
+__global__ __launch_bounds__(256) void dmh_resize_kernel(const __bf16 *__restrict__ logits, const int H, const int W,
+                                                         const int TR, const int nbands, const int th, const int tw,
+                                                         __bf16 *__restrict__ up, unsigned char *__restrict__ amask)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float *tile = reinterpret_cast<float *>(smem_raw);
+  const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int nq = (int)(lb / (unsigned)nbands);
+  const int band = (int)(lb - (unsigned)nq * nbands);
+  const int r0 = band * TR, r1 = min(r0 + TR, H);
+  const int lo = max(r0 - 1, 0), hi = min(r1, H - 1);
+  const int npx = (hi - lo + 1) * W;
+  const __bf16 *src = logits + (size_t)nq * H * W + (size_t)lo * W;
+  if ((W & 7) == 0) {        // 16-byte loads: rows are multiples of 8 bf16 and the band starts on a row boundary
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    for (int i = threadIdx.x * 8; i < npx; i += 256 * 8) {
+      const bf16x8_t v = *reinterpret_cast<const bf16x8_t *>(src + i);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tile[i + k] = (float)v[k];
+    }
+  } else {
+    for (int i = threadIdx.x; i < npx; i += 256) tile[i] = (float)src[i];
+  }
+  __syncthreads();
+
+  {
+    const int OW = 2 * W, OH = 2 * H;
+    __bf16 *uplane = up + (size_t)nq * OH * OW;
+    const int orow0 = 2 * r0, orows = 2 * (r1 - r0);
+    if ((OW & 7) == 0) {     // 8 outputs (16 bytes) per lane
+      typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+      const int qpr = OW / 8;
+      for (int i = threadIdx.x; i < orows * qpr; i += 256) {
+        const int orr = i / qpr, oq = i - orr * qpr;
+        const int oy = orow0 + orr;
+        int y0, y1;
+        float ly;
+        dm_bilinear_src(oy, 0.5f, H, y0, y1, ly);
+        const float *ra = tile + (y0 - lo) * W, *rb = tile + (y1 - lo) * W;
+        bf16x8_t o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          int x0, x1;
+          float lxx;
+          dm_bilinear_src(oq * 8 + k, 0.5f, W, x0, x1, lxx);
+          o[k] = (__bf16)((1.f - ly) * ((1.f - lxx) * ra[x0] + lxx * ra[x1]) +
+                          ly * ((1.f - lxx) * rb[x0] + lxx * rb[x1]));
+        }
+        *reinterpret_cast<bf16x8_t *>(uplane + (size_t)oy * OW + oq * 8) = o;
+      }
+    } else {
+      for (int i = threadIdx.x; i < orows * OW; i += 256) {
+        const int orr = i / OW, ox = i - orr * OW;
+        const int oy = orow0 + orr;
+        int y0, y1, x0, x1;
+        float ly, lxx;
+        dm_bilinear_src(oy, 0.5f, H, y0, y1, ly);
+        dm_bilinear_src(ox, 0.5f, W, x0, x1, lxx);
+        const float *ra = tile + (y0 - lo) * W, *rb = tile + (y1 - lo) * W;
+        uplane[(size_t)oy * OW + ox] =
+            (__bf16)((1.f - ly) * ((1.f - lxx) * ra[x0] + lxx * ra[x1]) + ly * ((1.f - lxx) * rb[x0] + lxx * rb[x1]));
+      }
+    }
+  }
+  {
+    const float sh = (float)H / (float)th, sw = (float)W / (float)tw;
+    unsigned char *mplane = amask + (size_t)nq * th * tw;
+    for (int i = threadIdx.x; i < th * tw; i += 256) {
+      const int ty = i / tw, tx = i - ty * tw;
+      int y0, y1, x0, x1;
+      float ly, lxx;
+      dm_bilinear_src(ty, sh, H, y0, y1, ly);
+      if (y0 < r0 || y0 >= r1) continue;
+      dm_bilinear_src(tx, sw, W, x0, x1, lxx);
+      const float *ra = tile + (y0 - lo) * W, *rb = tile + (y1 - lo) * W;
+      float v = (1.f - ly) * ((1.f - lxx) * ra[x0] + lxx * ra[x1]) + ly * ((1.f - lxx) * rb[x0] + lxx * rb[x1]);
+      v = (float)(__bf16)v;                                          // torch's bf16 interpolate output
+      const float s = (float)(__bf16)(1.f / (1.f + expf(-v)));       // ... and bf16 sigmoid
+      mplane[i] = s < 0.5f ? 1 : 0;
+    }
+  }
+}
+
+// `scratch` : [N, Q, H*W] bf16 workspace for the logits (caller-allocated; no allocation inside the launch path)
+int launch_dyn_mask_head_mfma(const float *feat, const float *ref, const float *params, int N, int C, int Q, int H,
+                              int W, int stride, int rel_coord, int th, int tw, void *scratch, void *up,
+                              unsigned char *amask, hipStream_t stream)
+{
+  if (C != 16) return -4;
+  if ((long long)N * Q == 0 || H == 0 || W == 0) return 0;
+  const int HW = H * W;
+  const int px_per_block = (DMM_BLOCK / 64) * DMM_PT * 16;
+  const int bpi = (HW + px_per_block - 1) / px_per_block;
+  __bf16 *lg = static_cast<__bf16 *>(scratch);
+  if (rel_coord)
+    hipLaunchKernelGGL((dmh_logits_mfma_kernel<true>), dim3((unsigned)(N * bpi)), dim3(DMM_BLOCK), 0, stream, feat, ref,
+                       params, Q, H, W, stride, bpi, lg);
+  else
+    hipLaunchKernelGGL((dmh_logits_mfma_kernel<false>), dim3((unsigned)(N * bpi)), dim3(DMM_BLOCK), 0, stream, feat, ref,
+                       params, Q, H, W, stride, bpi, lg);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+
+  int TR = H;
+  const int max_rows = (48 * 1024) / (W * 4) - 2;
+  if (max_rows < 1) return -4;
+  if (TR > max_rows) TR = max_rows;
+  while (TR > 8 && (long long)N * Q * ((H + TR - 1) / TR) < 4096) TR = (TR + 1) / 2;
+  const int nbands = (H + TR - 1) / TR;
+  const long long nblk = (long long)N * Q * nbands;
+  if (nblk > 0x7fffffffLL) return -4;
+  hipLaunchKernelGGL(dmh_resize_kernel, dim3((unsigned)nblk), dim3(256), (size_t)(TR + 2) * W * sizeof(float), stream, lg,
+                     H, W, TR, nbands, th, tw, static_cast<__bf16 *>(up), amask);
+  return (int)hipGetLastError();
+}
+
+}  // namespace pct

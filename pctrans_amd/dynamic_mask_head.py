@@ -1,6 +1,8 @@
 """Python entry of the fused dynamic mask head kernel (C ABI `pct_dynamic_mask_head_forward`,
 include/pctrans_hip.h; kernel pctrans_amd/csrc/dyn_mask_head.hip).  Forward only: when gradients are needed the
 decoder uses its differentiable batched formulation instead (mask2former_transformer_decoder.py in this package)."""
+import os
+
 import torch
 
 from . import _lib
@@ -32,6 +34,16 @@ def dynamic_mask_head_forward(mask_feats, ref_xy, params, stride, rel_coord, tar
     th, tw = int(target_size[0]), int(target_size[1])
     up = torch.empty((N, Q, 2 * H, 2 * W), dtype=out_dtype, device=mask_feats.device)
     amask = torch.empty((N, Q, th * tw), dtype=torch.bool, device=mask_feats.device)
+    if out_dtype == torch.bfloat16 and os.environ.get("PCT_DMH_KERNEL", "mfma") != "valu":
+        # bf16-autocast configuration: MLP on MFMA + streaming resize (two launches, bf16 logits workspace)
+        scratch = torch.empty((N, Q, H, W), dtype=torch.bfloat16, device=mask_feats.device)
+        with torch.cuda.device(mask_feats.device):
+            rc = _lib.lib().pct_dynamic_mask_head_forward_mfma(
+                feats.data_ptr(), ref.data_ptr() if rel_coord else None, prm.data_ptr(), N, C, Q, H, W, int(stride),
+                1 if rel_coord else 0, th, tw, scratch.data_ptr(), up.data_ptr(), amask.data_ptr(),
+                torch.cuda.current_stream(mask_feats.device).cuda_stream)
+        _lib.check(rc, "dynamic_mask_head_forward_mfma")
+        return up, amask
     with torch.cuda.device(mask_feats.device):
         rc = _lib.lib().pct_dynamic_mask_head_forward(
             feats.data_ptr(), ref.data_ptr() if rel_coord else None, prm.data_ptr(), N, C, Q, H, W, int(stride),

@@ -47,25 +47,49 @@ def test_fused_mask_head_fp32(N, Q, H, W, target):
     assert differ.float().mean() < 1e-3
 
 
-def test_fused_mask_head_bf16_output_matches_autocast_semantics():
-    """bf16 mode: logits rounded to bf16 (as the reference's autocast convs emit), resized with fp32 math, stored
-    as bf16.  Compared with the same pipeline built from torch bf16 ops on the fp32 kernel's logits."""
+def _bf16_chain_reference(mf, ref, prm, stride=4):
+    """The autocast pipeline the bf16 kernels implement, from torch ops: features / generated weights / hidden
+    activations rounded to bf16 (what bf16 convolutions see), fp32 accumulation, rel-coord term and biases in fp32."""
+    N, C, H, W = mf.shape
+    Q = ref.shape[0]
+    r = lambda t: t.bfloat16().float()
+    p = prm.transpose(0, 1).float()                                       # [N, Q, 233]
+    w0 = p[..., :144].reshape(N, Q, 8, 18)
+    w1, w2 = p[..., 144:208].reshape(N, Q, 8, 8), p[..., 208:216].reshape(N, Q, 1, 8)
+    b0, b1, b2 = p[..., 216:224], p[..., 224:232], p[..., 232:233]
+    f = r(mf.float()).reshape(N, 1, C, H * W)
+    inst = ref.transpose(0, 1).float() * torch.tensor([W * stride, H * stride], dtype=torch.float32, device=mf.device)
+    ys, xs = torch.meshgrid(torch.arange(H, device=mf.device), torch.arange(W, device=mf.device), indexing="ij")
+    loc = torch.stack([xs.reshape(-1), ys.reshape(-1)], 1).float() * stride + stride // 2
+    rel = inst[:, :, None, :] - loc[None, None]                           # [N, Q, HW, 2]
+    x = r(w0[..., 2:]) @ f + w0[..., 0:1] * rel[:, :, None, :, 0] + w0[..., 1:2] * rel[:, :, None, :, 1] + b0[..., None]
+    x = r(torch.relu(x))
+    x = torch.relu(r(w1) @ x + b1[..., None])
+    return ((w2 @ x) + b2[..., None]).reshape(N, Q, H, W)
+
+
+@pytest.mark.parametrize("kernel", ["mfma", "valu"])
+@pytest.mark.parametrize("N,Q,H,W,target", [(2, 100, 64, 64, (16, 16)), (1, 101, 128, 128, (64, 64)),
+                                            (2, 7, 33, 20, (9, 5))])
+def test_fused_mask_head_bf16_output_matches_autocast_semantics(monkeypatch, kernel, N, Q, H, W, target):
+    """bf16 mode: MFMA kernels (bf16 operands, default) and the fp32-VALU kernel (logits rounded to bf16 afterwards)
+    against the torch emulation of the autocast pipeline; resized with fp32 math, stored as bf16."""
     from pctrans_amd import dynamic_mask_head as dmh
-    N, Q, H, W, target = 2, 100, 64, 64, (16, 16)
-    d = _small_decoder(Q=Q).double()
+    monkeypatch.setenv("PCT_DMH_KERNEL", kernel)
     mf, ref, prm = _case(N, Q, H, W, seed=5)
-    want = _reference_formulation(d, mf, ref, prm).float().cuda()
-    args = (mf.float().cuda(), ref.transpose(0, 1).float().cuda(), prm.transpose(0, 1).float().cuda(), 4, True, target)
-    up, amask = dmh.dynamic_mask_head_forward(*args, out_dtype=torch.bfloat16)
-    assert up.dtype == torch.bfloat16
+    mf, ref, prm = mf.float().cuda(), ref.float().cuda(), prm.float().cuda()
+    want = _bf16_chain_reference(mf, ref, prm)
+    up, amask = dmh.dynamic_mask_head_forward(mf, ref.transpose(0, 1), prm.transpose(0, 1), 4, True, target,
+                                              out_dtype=torch.bfloat16)
+    assert up.dtype == torch.bfloat16 and up.shape == (N, Q, 2 * H, 2 * W)
     lb = want.bfloat16()
     want_up = F.interpolate(lb, size=(2 * H, 2 * W), mode="bilinear", align_corners=False)
-    # logits within 1 bf16 ulp of a rounding boundary may round differently: allow 2^-7 relative on a tiny fraction
+    # hidden activations near a bf16 rounding boundary may round differently: a few bf16 ulps on a small fraction
     diff = (up.float() - want_up.float()).abs()
-    tol = want_up.float().abs() * 2.0 ** -7 + 1e-3
-    assert (diff <= tol).float().mean() > 0.999
+    tol = want_up.float().abs() * 2.0 ** -6 + 3e-2
+    assert (diff <= tol).float().mean() > 0.995, float((diff <= tol).float().mean())
     want_m = F.interpolate(lb, size=target, mode="bilinear", align_corners=False).sigmoid().flatten(2) < 0.5
-    assert (amask != want_m).float().mean() < 5e-3
+    assert (amask != want_m).float().mean() < 1e-2
 
 
 def test_decoder_uses_fused_kernel_and_matches_batched_formulation():
