@@ -90,6 +90,23 @@ def cpu_baseline(args, levels_hw):
             "ms_per_image_layer": 1e3 * el / reps, "algorithmic_GBps": alg_bytes * reps / el / 1e9}
 
 
+def traffic_from_profile(args):
+    """HBM bytes per launch of the MSDeformAttn kernel from the PMC passes committed under profiles/ (collected with
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE ...` around this very script; bench.py cannot read counters
+    itself).  Only reported when the committed measurement is for this workload; raw counter bytes, see the file's note
+    on FETCH_SIZE calibration."""
+    path = os.path.join(ROOT, "profiles", "r01_msda_traffic_batch%d.json" % args.batch)
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("batch") == args.batch and t.get("levels") == args.levels and args.image == 512:
+            return {"bytes": t["hbm_bytes_raw"], "bytes_if_fetch_doubled": t["hbm_bytes_fetch_doubled"],
+                    "source": os.path.relpath(path, ROOT)}
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -172,9 +189,10 @@ def main():
                 "queries": args.queries, "parallelism": "dp%d (images sharded, no data-path collective)" % world,
             },
             "roofline": {
-                "kernel": "pct::msda_forward_dpp_kernel<float,16,4,qmajor,fused> (MSDeformAttn forward incl. softmax + location math)",
+                "kernel": "pct::msda_forward_win_kernel<float,16,L,4,NS=4,fused> (MSDeformAttn forward incl. softmax + "
+                          "location math; windowed-LDS gather)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic_from_profile(args),
                 "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_ms, "launches_timed": len(fwd),
                 "share_of_step": (sum(fwd) / (1e3 * elapsed)) if fwd else None,
             },
