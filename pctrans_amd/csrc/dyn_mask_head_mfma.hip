@@ -168,26 +168,59 @@ __global__ __launch_bounds__(256) void dmh_resize_kernel(const __bf16 *__restric
     const int OW = 2 * W, OH = 2 * H;
     __bf16 *uplane = up + (size_t)nq * OH * OW;
     const int orow0 = 2 * r0, orows = 2 * (r1 - r0);
-    if ((OW & 7) == 0) {     // 8 outputs (16 bytes) per lane
+    if ((W & 3) == 0) {
+      // exact-x2 fast path: a lane takes 4 input columns of one input row y and emits the 8 outputs of BOTH output rows
+      // 2y and 2y+1 (two 16-byte stores).  At scale 1/2 PyTorch's source index is dst/2 - 1/4: weights are exactly
+      // (1/4, 3/4) / (3/4, 1/4), clamped at the borders (lambda = 0 at the low edge, replicated index at the high
+      // edge), so the generic formula below is evaluated with constant weights -- bit-identical to the generic path.
       typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-      const int qpr = OW / 8;
-      for (int i = threadIdx.x; i < orows * qpr; i += 256) {
-        const int orr = i / qpr, oq = i - orr * qpr;
-        const int oy = orow0 + orr;
-        int y0, y1;
-        float ly;
-        dm_bilinear_src(oy, 0.5f, H, y0, y1, ly);
-        const float *ra = tile + (y0 - lo) * W, *rb = tile + (y1 - lo) * W;
-        bf16x8_t o;
+      const int cpr = W / 4;                                        // 4-column groups per row
+      const int nrows_b = r1 - r0;
+      for (int i = threadIdx.x; i < nrows_b * cpr; i += 256) {
+        const int ry = i / cpr, cg = i - ry * cpr;
+        const int y = r0 + ry, x0 = cg * 4;
+        const float *rm = tile + (max(y - 1, 0) - lo) * W;         // rows y-1, y, y+1 (clamped like the index clamp)
+        const float *rc = tile + (y - lo) * W;
+        const float *rp = tile + (min(y + 1, H - 1) - lo) * W;
+        float m[6], c[6], p[6];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          int x0, x1;
-          float lxx;
-          dm_bilinear_src(oq * 8 + k, 0.5f, W, x0, x1, lxx);
-          o[k] = (__bf16)((1.f - ly) * ((1.f - lxx) * ra[x0] + lxx * ra[x1]) +
-                          ly * ((1.f - lxx) * rb[x0] + lxx * rb[x1]));
+        for (int k = 0; k < 6; ++k) {
+          const int x = min(max(x0 - 1 + k, 0), W - 1);
+          m[k] = rm[x];
+          c[k] = rc[x];
+          p[k] = rp[x];
         }
-        *reinterpret_cast<bf16x8_t *>(uplane + (size_t)oy * OW + oq * 8) = o;
+        // output row 2y: source rows (y-1, y), weights (1/4, 3/4); y = 0: source rows (0, 1), weights (1, 0).
+        // output row 2y+1: source rows (y, y+1), weights (3/4, 1/4).  Register selects only (no runtime-indexed arrays).
+        const bool top = y == 0;
+        const float hA0 = top ? 1.f : 0.25f, hA1 = top ? 0.f : 0.75f;
+        float a0[6], a1[6];                                         // the two source rows of output row 2y
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          a0[k] = top ? c[k] : m[k];
+          a1[k] = top ? p[k] : c[k];
+        }
+        bf16x8_t oa, ob;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // even output column 2xx: source cols (xx-1, xx) = entries (k, k+1), weights (1/4, 3/4);
+          // xx = 0: source cols (0, 1) = entries (k+1, k+2), weights (1, 0)
+          const bool left = x0 + k == 0;
+          const float wl0 = left ? 1.f : 0.25f, wl1 = left ? 0.f : 0.75f;
+          const float a0l = left ? a0[k + 1] : a0[k], a0r = left ? a0[k + 2] : a0[k + 1];
+          const float a1l = left ? a1[k + 1] : a1[k], a1r = left ? a1[k + 2] : a1[k + 1];
+          const float c_l = left ? c[k + 1] : c[k], c_r = left ? c[k + 2] : c[k + 1];
+          const float p_l = left ? p[k + 1] : p[k], p_r = left ? p[k + 2] : p[k + 1];
+          oa[2 * k] = (__bf16)(hA0 * (wl0 * a0l + wl1 * a0r) + hA1 * (wl0 * a1l + wl1 * a1r));
+          ob[2 * k] = (__bf16)(0.75f * (wl0 * c_l + wl1 * c_r) + 0.25f * (wl0 * p_l + wl1 * p_r));
+          // odd output column 2xx+1: source cols (xx, xx+1) = entries (k+1, k+2), weights (3/4, 1/4)
+          oa[2 * k + 1] = (__bf16)(hA0 * (0.75f * a0[k + 1] + 0.25f * a0[k + 2]) +
+                                   hA1 * (0.75f * a1[k + 1] + 0.25f * a1[k + 2]));
+          ob[2 * k + 1] = (__bf16)(0.75f * (0.75f * c[k + 1] + 0.25f * c[k + 2]) +
+                                   0.25f * (0.75f * p[k + 1] + 0.25f * p[k + 2]));
+        }
+        *reinterpret_cast<bf16x8_t *>(uplane + (size_t)(2 * y) * OW + 2 * x0) = oa;
+        *reinterpret_cast<bf16x8_t *>(uplane + (size_t)(2 * y + 1) * OW + 2 * x0) = ob;
       }
     } else {
       for (int i = threadIdx.x; i < orows * OW; i += 256) {
@@ -206,7 +239,10 @@ __global__ __launch_bounds__(256) void dmh_resize_kernel(const __bf16 *__restric
   {
     const float sh = (float)H / (float)th, sw = (float)W / (float)tw;
     unsigned char *mplane = amask + (size_t)nq * th * tw;
-    for (int i = threadIdx.x; i < th * tw; i += 256) {
+    // only target rows whose upper source row can fall into [r0, r1): ty in [(r0+0.5)/sh - 1.5, (r1+0.5)/sh + 0.5]
+    const int ty_lo = max(0, (int)(((float)r0 + 0.5f) / sh - 1.5f));
+    const int ty_hi = min(th, (int)(((float)r1 + 0.5f) / sh + 0.5f) + 1);
+    for (int i = ty_lo * tw + threadIdx.x; i < ty_hi * tw; i += 256) {
       const int ty = i / tw, tx = i - ty * tw;
       int y0, y1, x0, x1;
       float ly, lxx;
@@ -243,7 +279,7 @@ int launch_dyn_mask_head_mfma(const float *feat, const float *ref, const float *
   if (e != hipSuccess) return (int)e;
 
   int TR = H;
-  const int max_rows = (48 * 1024) / (W * 4) - 2;
+  const int max_rows = (16 * 1024) / (W * 4) - 2;                 // <= 16 KB of LDS per block: many blocks per CU
   if (max_rows < 1) return -4;
   if (TR > max_rows) TR = max_rows;
   while (TR > 8 && (long long)N * Q * ((H + TR - 1) / TR) < 4096) TR = (TR + 1) / 2;
