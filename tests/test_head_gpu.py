@@ -100,3 +100,34 @@ def test_maskformer_train_step_and_eval_on_gpu():
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         out, _ = model(vol)
     assert out.shape == (2, H, W) and out.dtype == torch.int16
+
+
+@pytest.mark.parametrize("name,depth,H,W,Q,levels,N", [
+    ("cfg1_cvppp_tile_r18_q50", 18, 256, 256, 50, 3, 1),
+    ("cfg3_cvppp_val_530x500", 50, 544, 512, 100, 3, 2),          # 530x500 padded to SIZE_DIVISIBILITY 32
+    ("cfg4_bbbc_520x696_q300", 50, 544, 704, 300, 3, 2),          # 520x696 padded to /32
+    ("cfg2_north_star_l4", 50, 512, 512, 100, 4, 2),
+])
+def test_head_runs_on_every_baseline_config_shape(name, depth, H, W, Q, levels, N):
+    """BASELINE.json configs as head-level shapes (R18 / R50 channel counts, 50/100/300 queries, non-square,
+    non-power-of-two pyramids): fused path under bf16 autocast is finite and consistent with the fp32 run."""
+    from pctrans_amd.config import get_cfg, resnet_output_shape
+    from pctrans_amd.meta_arch.mask_former_head import MaskFormerHead
+    torch.manual_seed(0)
+    feats_in = ("res2", "res3", "res4", "res5")[4 - levels:]
+    cfg = get_cfg(num_queries=Q, enc_in_features=feats_in, norm="BN", sem_norm="BN")
+    shapes = resnet_output_shape(depth)
+    head = MaskFormerHead(**MaskFormerHead.from_config(cfg, shapes)).cuda().eval()
+    feats = _feats(shapes, N, H, W)
+    with torch.no_grad():
+        p32, mf = head(feats)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            p16, _ = head(feats)
+    hm, wm = (H // 4, W // 4) if levels == 4 else (H // 8, W // 8)
+    assert mf.shape == (N, 128, hm, wm)
+    assert p32["pred_masks"].shape == (N, Q, 2 * hm, 2 * wm) and p16["pred_masks"].shape == (N, Q, 2 * hm, 2 * wm)
+    assert torch.isfinite(p32["pred_masks"]).all() and torch.isfinite(p16["pred_masks"].float()).all()
+    assert len(p16["aux_outputs"]) == 9 and p16["reference_points"].shape == (N, Q, 2)
+    scale = max(1.0, float(p32["pred_masks"].abs().max()))
+    close = ((p16["pred_masks"].float() - p32["pred_masks"]).abs() <= 0.15 * scale).float().mean()
+    assert float(close) > 0.85, float(close)
