@@ -12,6 +12,9 @@
 // the three channel sums are xor-butterflies in registers.  Their results overwrite the record's staged
 // (x,y,weight) slots in LDS and leave the block as coalesced 16-byte stores.  grad_value uses hardware float
 // atomics (global_atomic_add_f32 / _f64), 64 contiguous bytes per record-corner.
+#include <stdlib.h>
+#include <string.h>
+
 #include "msda_common.hpp"
 
 namespace pct {
@@ -123,9 +126,10 @@ __global__ __launch_bounds__(BWD_BLOCK) void msda_backward_kernel(
         g_a += __shfl_xor(g_a, o);
       }
       if (cv == 0 && active) {  // every lane of the record has read slot sidx already (same wave, in order)
-        rl[2 * sidx] = g_w;
-        rl[2 * sidx + 1] = g_h;
-        rw[sidx] = g_a;
+        // a gated-out sample is skipped by the reference (cuh:352): exact zeros even when grad_out is not finite
+        rl[2 * sidx] = gate ? g_w : (A)0;
+        rl[2 * sidx + 1] = gate ? g_h : (A)0;
+        rw[sidx] = gate ? g_a : (A)0;
       }
     } else {
       if (gate) {
@@ -162,6 +166,10 @@ __global__ __launch_bounds__(BWD_BLOCK) void msda_backward_kernel(
   }
 }
 
+int launch_msda_backward_win(const float *value, const int64_t *shapes, const int64_t *starts, const float *loc,
+                             const float *attn, const float *grad_out, int N, int S, int M, int D, int L, int Lq,
+                             int P, float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream);
+
 template <typename A>
 int launch_msda_backward(const void *value, const int64_t *shapes, const int64_t *starts, const void *loc,
                          const void *attn, const void *grad_out, int N, int S, int M, int D, int L, int Lq,
@@ -184,6 +192,20 @@ int launch_msda_backward(const void *value, const int64_t *shapes, const int64_t
     if (e != hipSuccess) return (int)e;
   }
   if (total_lanes == 0) return 0;
+  if constexpr (sizeof(A) == 4) {
+    // PCT_MSDA_BWD_KERNEL = auto (windowed when the queries are the pyramid's own pixels) | win | generic
+    static const int mode = [] {
+      const char *e = getenv("PCT_MSDA_BWD_KERNEL");
+      return !e ? 0 : (!strcmp(e, "win") ? 1 : (!strcmp(e, "generic") ? 2 : 0));
+    }();
+    if (shfl && mode != 2 && (mode == 1 || Lq == S)) {
+      const int rc = launch_msda_backward_win(
+          static_cast<const float *>(value), shapes, starts, static_cast<const float *>(loc),
+          static_cast<const float *>(attn), static_cast<const float *>(grad_out), N, S, M, D, L, Lq, P,
+          static_cast<float *>(grad_value), static_cast<float *>(grad_loc), static_cast<float *>(grad_attn), stream);
+      if (rc != -100) return rc;
+    }
+  }
   const long long nblk = (total_lanes + BWD_BLOCK - 1) / BWD_BLOCK;
   if (nblk > 0x7fffffffLL) return -4;
   const int rec_stride = sizeof(A) == 4 ? padded_record_stride(LP * 3) : LP * 3 + 1;

@@ -26,86 +26,9 @@
 
 #include <utility>
 
-#include "msda_common.hpp"
+#include "msda_win_common.hpp"
 
 namespace pct {
-
-constexpr int WIN_BLOCK = 256;
-constexpr int WIN_TH = 8;              // tile height in pyramid mode (tile width = TQ / 8)
-constexpr int WIN_MAXL = 8;
-
-__device__ const float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // source of the zero apron texels
-
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pk_min(unsigned a, unsigned b)
-{
-  return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
-}
-__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b)
-{
-  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
-}
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_u(unsigned v)
-{
-  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v)
-{
-  const int i = __builtin_bit_cast(int, v);
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, true));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v)
-{
-  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, true);
-}
-// quad_perm control that makes every lane of a QL-lane group read lane `src` of its own group
-template <int QL, int SRC>
-struct BcastCtrl {
-  static constexpr int value = QL == 4 ? (SRC | (SRC << 2) | (SRC << 4) | (SRC << 6))
-                                       : (SRC | (SRC << 2) | ((2 + SRC) << 4) | ((2 + SRC) << 6));
-};
-
-// full-wave reduction of packed (u16, u16) values; result in every lane (uniform)
-template <bool IS_MIN>
-__device__ __forceinline__ unsigned wave_reduce_pk(unsigned v)
-{
-  auto op = [](unsigned a, unsigned b) { return IS_MIN ? pk_min(a, b) : pk_max(a, b); };
-  v = op(v, dpp_u<0xB1>(v));    // quad_perm [1,0,3,2]
-  v = op(v, dpp_u<0x4E>(v));    // quad_perm [2,3,0,1]
-  v = op(v, dpp_u<0x141>(v));   // row_half_mirror
-  v = op(v, dpp_u<0x140>(v));   // row_mirror
-  const unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
-  const unsigned r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
-  return op(op(r0, r1), op(r2, r3));
-}
-
-// One level's window, derived identically by every lane from the 4 per-wave boxes in LDS.
-struct LevelWindow {
-  int x0, y0, wid, size;   // origin, width (pixels), pixel count (0 = no gated sample on this level)
-};
-__device__ __forceinline__ LevelWindow read_window(const unsigned *bb, const int L, const int l)
-{
-  unsigned lo = bb[l * 2], hi = bb[l * 2 + 1];
-#pragma unroll
-  for (int w = 1; w < WIN_BLOCK / 64; ++w) {
-    lo = pk_min(lo, bb[(w * L + l) * 2]);
-    hi = pk_max(hi, bb[(w * L + l) * 2 + 1]);
-  }
-  lo = __builtin_amdgcn_readfirstlane(lo);
-  hi = __builtin_amdgcn_readfirstlane(hi);
-  const int x0 = (int)(lo & 0xFFFFu) - 1, y0 = (int)(lo >> 16) - 1;      // un-bias: origin may be -1 (apron)
-  const int x1 = (int)(hi & 0xFFFFu) - 1, y1 = (int)(hi >> 16) - 1;
-  LevelWindow w;
-  const bool empty = x0 > x1 || y0 > y1;
-  w.x0 = x0;
-  w.y0 = y0;
-  w.wid = empty ? 1 : x1 - x0 + 1;
-  w.size = empty ? 0 : w.wid * (y1 - y0 + 1);
-  return w;
-}
 
 // NS = query slots per lane: one work item covers NS * (256 / QL) queries, so the per-item work (bounding boxes,
 // window set-up, staging, barriers) is amortised over NS gathers.

@@ -284,6 +284,80 @@ def test_windowed_kernel_16bit(MSDA, tdt, eps):
     assert np.all(err <= eps * np.abs(want) + 1e-5), float(err.max())
 
 
+BWD_WIN_CASES = [c for c in WIN_CASES if c[1]["P"] == 4]
+
+
+@pytest.mark.parametrize("cid,kw", BWD_WIN_CASES, ids=[c[0] for c in BWD_WIN_CASES])
+def test_backward_windowed_kernel_vs_oracle(MSDA, cid, kw):
+    """Large pyramid-mode problems take msda_backward_win.hip (LDS-window accumulation, one flush per window); the
+    uniform / spilled cases exercise its per-level direct path, the Lq != S case the generic kernel."""
+    c = make_case(dtype=np.float32, **kw)
+    N, Lq = c["loc"].shape[:2]
+    go = np.random.RandomState(kw["seed"] + 100).standard_normal((N, Lq, 8 * 16 if kw["M"] == 8 else kw["M"] * 16))
+    go = go.astype(np.float32)
+    want = orc.backward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"], go)
+    got = run_bwd(MSDA, c, go)
+    # grad_loc is discontinuous where a sample sits on a cell boundary (floor() flips): the kernel forms loc*W-0.5
+    # with one FMA, the oracle with two roundings, so samples within 1e-3 px of a boundary are not compared
+    wh = np.stack([c["shapes"][:, 1], c["shapes"][:, 0]], -1).astype(np.float64)          # (W, H) per level
+    pix = c["loc"].astype(np.float64) * wh[None, None, None, :, None, :] - 0.5
+    on_edge = (np.abs(pix - np.round(pix)) < 1e-3).any(-1, keepdims=True)
+    assert on_edge.mean() < 0.01
+    for g, w, name in zip(got, want, ("grad_value", "grad_loc", "grad_attn")):
+        scale = max(1.0, float(np.abs(w).max()))
+        if name == "grad_loc":
+            g, w = np.where(on_edge, 0, g), np.where(on_edge, 0, w)
+        np.testing.assert_allclose(g, w, rtol=0, atol=2e-5 * scale, err_msg=name)
+
+
+@pytest.mark.parametrize("go_scale", [1e-20, 1.0, 1e20])
+def test_backward_windowed_fixed_point_follows_the_gradient_scale(MSDA, go_scale):
+    """The LDS accumulators are int32 fixed point with a per-tile power-of-two scale taken from max|grad_out| *
+    max|attn|: the error stays relative to the gradient's own magnitude over 40 orders of magnitude."""
+    c = make_case(seed=74, N=1, M=8, D=16, Lq=5376, P=4, shapes=[(16, 16), (32, 32), (64, 64)], model_like=True)
+    go = (np.random.RandomState(174).standard_normal((1, 5376, 128)) * go_scale).astype(np.float32)
+    want = orc.backward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"], go)
+    got = run_bwd(MSDA, c, go)
+    for g, w, name in zip(got, want, ("grad_value", "grad_attn")):
+        np.testing.assert_allclose(g / go_scale, w / go_scale, rtol=0,
+                                   atol=2e-5 * max(1.0, float(np.abs(w / go_scale).max())), err_msg=name)
+
+
+def test_backward_windowed_nonfinite_grad_out_takes_the_float_path(MSDA):
+    """A tile whose grad_out holds Inf / NaN cannot be scaled to fixed point: it must produce what float atomics do."""
+    c = make_case(seed=75, N=1, M=8, D=16, Lq=5376, P=4, shapes=[(16, 16), (32, 32), (64, 64)], model_like=True)
+    go = np.random.RandomState(175).standard_normal((1, 5376, 128)).astype(np.float32)
+    go[0, 3000, 17] = np.inf
+    go[0, 4100, 90] = np.nan
+    want = orc.backward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"], go)
+    got = run_bwd(MSDA, c, go)
+    for g, w, name in zip(got, want, ("grad_value", "grad_loc", "grad_attn")):
+        np.testing.assert_array_equal(np.isnan(g), np.isnan(w), err_msg=name)
+        np.testing.assert_array_equal(np.isposinf(g), np.isposinf(w), err_msg=name)
+        np.testing.assert_array_equal(np.isneginf(g), np.isneginf(w), err_msg=name)
+        fin = np.isfinite(w)
+        np.testing.assert_allclose(g[fin], w[fin], rtol=0, atol=2e-5 * max(1.0, float(np.abs(w[fin]).max())),
+                                   err_msg=name)
+
+
+def test_backward_windowed_gated_out_and_nonfinite_neighbours(MSDA):
+    """Samples outside the map get exactly-zero gradients, and an Inf texel only reaches the gradients of samples
+    that read it (the window's zero pixels / apron never inject 0 * Inf)."""
+    c = make_case(seed=73, N=1, M=8, D=16, Lq=5376, P=4, shapes=[(16, 16), (32, 32), (64, 64)], model_like=True,
+                  px_sigma=1.5)
+    c["loc"][0, ::7, :, :, 1, :] = -3.0                      # far outside: gated out
+    c["value"][0, 2000, 5, :] = np.inf
+    go = np.random.RandomState(173).standard_normal((1, 5376, 128)).astype(np.float32)
+    want = orc.backward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"], go)
+    got = run_bwd(MSDA, c, go)
+    assert np.all(got[1][0, ::7, :, :, 1, :] == 0) and np.all(got[2][0, ::7, :, :, 1] == 0)
+    for g, w, name in zip(got, want, ("grad_value", "grad_loc", "grad_attn")):
+        np.testing.assert_array_equal(np.isfinite(g), np.isfinite(w), err_msg=name)
+        fin = np.isfinite(w)
+        scale = max(1.0, float(np.abs(w[fin]).max()))
+        np.testing.assert_allclose(g[fin], w[fin], rtol=0, atol=2e-5 * scale, err_msg=name)
+
+
 # ---------------------------------------------------------------- full-size properties -------------------------
 FULL = dict(N=8, M=8, D=16, P=4, shapes=[(16, 16), (32, 32), (64, 64), (128, 128)])   # north-star shape, Lq = S
 
@@ -395,3 +469,18 @@ def test_module_fused_path_matches_reference_module_golden(MSDA, golden):
     np.testing.assert_allclose(out2.detach().cpu().numpy(), g["out"], rtol=0, atol=1e-4)
     out2.sum().backward()
     assert m.value_proj.weight.grad is not None and torch.isfinite(m.sampling_offsets.weight.grad).all()
+
+
+def test_fullsize_backward_adjoint_identities(MSDA):
+    """At the north-star size (oracle too slow): the op is linear in `value` and in `attn`, so its backward is the
+    adjoint:  <go, forward(value)> == <grad_value, value> == <grad_attn, attn>."""
+    c = make_case(seed=81, model_like=True, Lq=21760, **FULL)
+    v, loc, attn = dev(c["value"]), dev(c["loc"]), dev(c["attn"])
+    sh, st = dev(c["shapes"]), dev(c["starts"])
+    go = torch.randn(FULL["N"], 21760, 128, device="cuda", generator=torch.Generator("cuda").manual_seed(5))
+    out = MSDA.ms_deform_attn_forward(v, sh, st, loc, attn, 64)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64)
+    lhs = (go.double() * out.double()).sum().item()
+    assert abs((gv.double() * v.double()).sum().item() - lhs) <= 1e-5 * abs(lhs) + 1e-2
+    assert abs((ga.double() * attn.double()).sum().item() - lhs) <= 1e-5 * abs(lhs) + 1e-2
+    assert torch.isfinite(gl).all()
