@@ -225,40 +225,62 @@ __global__ __launch_bounds__(WIN_BLOCK, 2) void msda_backward_win_kernel(
     const long long img_off = (long long)b * S * MD + m * D;        // this image, this head
     const float *vimg = value + img_off;
     float *gimg = grad_value + img_off;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      if (in_lds[l] && wsize[l] > 0) {
-        const float inv_w = 1.0f / (float)wwid[l];
-        const int n16 = wsize[l] * QL;
-        const float *vlev = vimg + (long long)St[l] * MD;
-        unsigned char *dst = vpool + (size_t)wbase[l] * PXB;
-        for (int it = 0; it * WIN_BLOCK < n16; ++it) {
-          const int i = it * WIN_BLOCK + tid;
-          if (i < n16) {
-            const int px = i / QL, cc = i & (QL - 1);
-            const int r = (int)(((float)px + 0.5f) * inv_w);
-            const int y = wy0[l] + r, x = wx0[l] + px - r * wwid[l];
-            const bool inside = y >= 0 && y < Hs[l] && x >= 0 && x < Ws[l];
-            const float *src = inside ? vlev + (long long)(y * Ws[l] + x) * MD + cc * VEC : g_zero16;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(src),
-                (__attribute__((address_space(3))) void *)(dst + (size_t)(it * WIN_BLOCK + (tid & ~63)) * 16), 16, 0, 0);
-          }
+    auto stage_window = [&](const int H, const int W, const int st, const int wb, const int wx, const int wy,
+                            const int ww, const int wsz) {
+      const float inv_w = 1.0f / (float)ww;
+      const int n16 = wsz * QL;
+      const float *vlev = vimg + (long long)st * MD;
+      unsigned char *dst = vpool + (size_t)wb * PXB;
+      for (int it = 0; it * WIN_BLOCK < n16; ++it) {
+        const int i = it * WIN_BLOCK + tid;
+        if (i < n16) {
+          const int px = i / QL, cc = i & (QL - 1);
+          const int r = (int)(((float)px + 0.5f) * inv_w);
+          const int y = wy + r, x = wx + px - r * ww;
+          const bool inside = y >= 0 && y < H && x >= 0 && x < W;
+          const float *src = inside ? vlev + (long long)(y * W + x) * MD + cc * VEC : g_zero16;
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void *)(src),
+              (__attribute__((address_space(3))) void *)(dst + (size_t)(it * WIN_BLOCK + (tid & ~63)) * 16), 16, 0, 0);
         }
       }
-    }
-    for (int i = tid; i < GPX * 4; i += WIN_BLOCK)                 // all 16 planes, 16 bytes at a time
-      reinterpret_cast<v4f *>(gpool)[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    };
+    auto zero_grad_pool = [&]() {
+      for (int i = tid; i < GPX * 4; i += WIN_BLOCK)               // all 16 planes, 16 bytes at a time
+        reinterpret_cast<v4f *>(gpool)[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    };
+    // one global atomic per window dword, lanes on consecutive dwords
+    auto flush_window = [&](const int H, const int W, const int st, const int wb, const int wx, const int wy,
+                            const int ww, const int wsz) {
+      const float inv_w = 1.0f / (float)ww;
+      const int n4 = wsz * (PXB / 4);
+      const int *srcw = gpool + wb;
+      float *glev = gimg + (long long)st * MD;
+      for (int i = tid; i < n4; i += WIN_BLOCK) {
+        const int px = i >> 4, ch = i & 15;
+        const int r = (int)(((float)px + 0.5f) * inv_w);
+        const int y = wy + r, x = wx + px - r * ww;
+        const bool inside = y >= 0 && y < H && x >= 0 && x < W;
+        const int gi = srcw[ch * GPX + px];
+        const float g = (float)gi * inv_scale;
+        if (inside && gi != 0) unsafeAtomicAdd(glev + (long long)(y * W + x) * MD + ch, g);
+      }
+    };
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+      if (in_lds[l] && wsize[l] > 0) stage_window(Hs[l], Ws[l], St[l], wbase[l], wx0[l], wy0[l], wwid[l], wsize[l]);
+    zero_grad_pool();
     __syncthreads();                                               // (2) windows staged / zeroed
 
     // ---- per slot: every lane walks the L*P samples of its query, geometry from the owner lane by DPP ----------
     const unsigned char *vlane = vpool + c * 16;
     int *glane = gpool + c * 4 * GPX;
-#pragma unroll 1
-    for (int s = 0; s < NS; ++s) {
-      long long rec = recs[0];
-      f32x2 sxy[L];
-      float sw[L];
+    const f32x2 sc2 = {scale, scale};
+    const f32x2 magic2 = {12582912.f, 12582912.f};                  // 1.5 * 2^23: fma(x, 1, magic) rounds x to an integer
+    // slot s of this lane: record, its point (p == c) of every level, its 4 channels of grad_out
+    auto select_slot = [&](const int s, long long &rec, f32x2 (&sxy)[L], float (&sw)[L], f32x2 (&top)[2]) {
+      rec = recs[0];
+      v4f tg = tops[0];
 #pragma unroll
       for (int l = 0; l < L; ++l) {
         sxy[l] = pxy[0][l];
@@ -272,37 +294,33 @@ __global__ __launch_bounds__(WIN_BLOCK, 2) void msda_backward_win_kernel(
           sxy[l] = s == u ? pxy[u][l] : sxy[l];
           sw[l] = s == u ? pw[u][l] : sw[l];
         }
-      }
-      const bool qvalid = rec >= 0;
-      v4f tg = tops[0];
-#pragma unroll
-      for (int u = 1; u < NS; ++u)
 #pragma unroll
         for (int k = 0; k < VEC; ++k) tg[k] = s == u ? tops[u][k] : tg[k];
-      const f32x2 top[2] = {f32x2{tg[0], tg[1]}, f32x2{tg[2], tg[3]}};
-      const f32x2 sc2 = {scale, scale};
-      const f32x2 magic2 = {12582912.f, 12582912.f};                // 1.5 * 2^23: fma(x, 1, magic) rounds x to an integer
-
-#pragma unroll
-      for (int l = 0; l < L; ++l) {
-        const int H = Hs[l], W = Ws[l];
-        const bool lds = in_lds[l] != 0;
+      }
+      top[0] = f32x2{tg[0], tg[1]};
+      top[1] = f32x2{tg[2], tg[3]};
+    };
+    // all P samples of one level of one slot.  lds: the level's window (base wb, origin wx/wy, width ww) is staged
+    auto do_level = [&](const int l, const int H, const int W, const int st, const long long rec, const f32x2 pt,
+                        const float wt, const f32x2 (&top)[2], const bool lds, const int wb, const int wx,
+                        const int wy, const int ww) {
+        const bool qvalid = rec >= 0;
         // owner side: my point of this level
-        const float h_im = sxy[l][1] * H - 0.5f, w_im = sxy[l][0] * W - 0.5f;
+        const float h_im = pt[1] * H - 0.5f, w_im = pt[0] * W - 0.5f;
         const bool gate = qvalid && h_im > -1 && w_im > -1 && h_im < H && w_im < W;
         const float hf = floorf(h_im), wf = floorf(w_im);
         const int y0 = gate ? (int)hf : 0, x0 = gate ? (int)wf : 0;
         const float o_lh = gate ? h_im - hf : 0.f, o_lw = gate ? w_im - wf : 0.f;   // gated-out: zero gradients
-        const float o_wgt = gate ? sw[l] : 0.f;
+        const float o_wgt = gate ? wt : 0.f;
         int o1, o2, o3 = 0, o4 = 0;
         if (lds) {
-          o1 = gate ? wbase[l] + __mul24(y0 - wy0[l], wwid[l]) + (x0 - wx0[l]) : 0;    // pixel index in the pool
-          o2 = gate ? wwid[l] : 0;                                                      // row step (pixels)
+          o1 = gate ? wb + __mul24(y0 - wy, ww) + (x0 - wx) : 0;                      // pixel index in the pool
+          o2 = gate ? ww : 0;                                                      // row step (pixels)
         } else {
           // element offsets from this image/head base; out-of-map corners -> -1
           const bool tp = gate && y0 >= 0, bt2 = gate && y0 + 1 <= H - 1;
           const bool lf = x0 >= 0, rg = x0 + 1 <= W - 1;
-          const int a = (St[l] + y0 * W + x0) * MD;
+          const int a = (st + y0 * W + x0) * MD;
           o1 = (tp && lf) ? a : -1;
           o2 = (tp && rg) ? a + MD : -1;
           o3 = (bt2 && lf) ? a + W * MD : -1;
@@ -437,26 +455,66 @@ __global__ __launch_bounds__(WIN_BLOCK, 2) void msda_backward_win_kernel(
               gate ? f32x2{my_gw, my_gh} : f32x2{0.f, 0.f};
           grad_attn[rec * (L * P) + l * P + c] = gate ? my_ga : 0.f;
         }
-      }
+    };
+
+    // a level whose tile-wide window did not fit is retried slot by slot (a slot's 64 queries cover half / a quarter
+    // of the footprint) once the pool is free again; only what still does not fit takes the direct path
+    bool defer[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) defer[l] = fixed_ok && !in_lds[l] && wsize[l] > 0;
+
+    // ---- main pass: per slot, every lane walks the samples of its query, geometry from the owner lane by DPP ----
+#pragma unroll 1
+    for (int s = 0; s < NS; ++s) {
+      long long rec;
+      f32x2 sxy[L], top[2];
+      float sw[L];
+      select_slot(s, rec, sxy, sw, top);
+#pragma unroll
+      for (int l = 0; l < L; ++l)
+        if (!defer[l])
+          do_level(l, Hs[l], Ws[l], St[l], rec, sxy[l], sw[l], top, in_lds[l] != 0, wbase[l], wx0[l], wy0[l], wwid[l]);
     }
     __syncthreads();                                               // (3) every add of this tile is in the windows
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+      if (in_lds[l] && wsize[l] > 0) flush_window(Hs[l], Ws[l], St[l], wbase[l], wx0[l], wy0[l], wwid[l], wsize[l]);
 
-    // ---- flush: one global atomic per window dword, lanes on consecutive dwords --------------------------------
+    // ---- deferred levels, one slot at a time ---------------------------------------------------------------------
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-      if (in_lds[l] && wsize[l] > 0) {
-        const float inv_w = 1.0f / (float)wwid[l];
-        const int n4 = wsize[l] * (PXB / 4);
-        const int *srcw = gpool + wbase[l];
-        float *glev = gimg + (long long)St[l] * MD;
-        for (int i = tid; i < n4; i += WIN_BLOCK) {
-          const int px = i >> 4, ch = i & 15;
-          const int r = (int)(((float)px + 0.5f) * inv_w);
-          const int y = wy0[l] + r, x = wx0[l] + px - r * wwid[l];
-          const bool inside = y >= 0 && y < Hs[l] && x >= 0 && x < Ws[l];
-          const int gi = srcw[ch * GPX + px];
-          const float g = (float)gi * inv_scale;
-          if (inside && gi != 0) unsafeAtomicAdd(glev + (long long)(y * Ws[l] + x) * MD + ch, g);
+      if (defer[l]) {                                               // uniform
+#pragma unroll 1
+        for (int s = 0; s < NS; ++s) {
+          long long rec;
+          f32x2 sxy[L], top[2];
+          float sw[L];
+          select_slot(s, rec, sxy, sw, top);
+          {
+            const float h_im = sxy[l][1] * Hs[l] - 0.5f, w_im = sxy[l][0] * Ws[l] - 0.5f;
+            const bool gate = rec >= 0 && h_im > -1 && w_im > -1 && h_im < Hs[l] && w_im < Ws[l];
+            const unsigned xa = (unsigned)((int)floorf(w_im) + 1), ya = (unsigned)((int)floorf(h_im) + 1);
+            const unsigned lo = wave_reduce_pk<true>(gate ? (xa | (ya << 16)) : 0xFFFFFFFFu);
+            const unsigned hi = wave_reduce_pk<false>(gate ? ((xa + 1) | ((ya + 1) << 16)) : 0u);
+            if ((tid & 63) == 0) {
+              bb[(wave * L + l) * 2] = lo;
+              bb[(wave * L + l) * 2 + 1] = hi;
+            }
+          }
+          __syncthreads();                                         // slot boxes visible; earlier flushes issued
+          const LevelWindow w = read_window(bb, L, l);
+          __syncthreads();                                         // everyone has read the boxes
+          const bool fits = w.size > 0 && w.size <= pool_px - 2;
+          if (fits) {
+            stage_window(Hs[l], Ws[l], St[l], 2, w.x0, w.y0, w.wid, w.size);
+            zero_grad_pool();
+            __syncthreads();
+          }
+          do_level(l, Hs[l], Ws[l], St[l], rec, sxy[l], sw[l], top, fits, 2, w.x0, w.y0, w.wid);
+          if (fits) {
+            __syncthreads();
+            flush_window(Hs[l], Ws[l], St[l], 2, w.x0, w.y0, w.wid, w.size);
+          }
         }
       }
     }

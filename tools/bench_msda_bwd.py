@@ -13,7 +13,7 @@ from pctrans_amd import MultiScaleDeformableAttention as MSDA  # noqa: E402
 
 for sname, N in (("P1", 8), ("P2", 2), ("P2", 8)):
     shapes, P = SHAPES[sname]
-    for dist in ("I", "U"):
+    for dist in ("I", "M", "U"):
         v, sh, st, loc, w = make(shapes, P, N, dist, torch.float32)
         go = torch.randn(N, v.shape[1], 128, device="cuda")
         for _ in range(3):
