@@ -108,16 +108,19 @@ __global__ __launch_bounds__(WIN_BLOCK, NS == 4 ? 3 : 4) void msda_forward_win_k
   const int chunk = (items + 7) / 8;
   const int item_end = min((xcd + 1) * chunk, items);
 
-  for (int item = xcd * chunk + slot0; item < item_end; item += nslots) {
-    stamp(-1);
-    const int m = item % M;
+  // Per item two barriers: (A) boxes visible + pool free, (B) windows staged.  The boxes of item i+1 are computed
+  // right after the gather of item i, into the other half of `bb`, so the waves that finish their gather early spend
+  // the wait on the next item's point loads instead of idling at a third barrier.
+  int m = 0, b = 0;
+  long long recs[NS];
+  int qidx[NS];                                                     // query index within the image (FUSED: ref row)
+  auto prepass = [&](const int item, unsigned *bbw) {
+    m = item % M;
     const int bt = item / M;
     const int t = bt % T_img;
-    const int b = bt / T_img;
+    b = bt / T_img;
 
     // ---- this lane's NS queries (record index or -1) -----------------------------------------------------------
-    long long recs[NS];
-    int qidx[NS];                                                   // query index within the image (FUSED: ref row)
     {
       int Hq = Hs[0], Wq = Ws[0], Sq = St[0], tb = 0;
       if (pyramid) {
@@ -182,13 +185,22 @@ __global__ __launch_bounds__(WIN_BLOCK, NS == 4 ? 3 : 4) void msda_forward_win_k
         lo = wave_reduce_pk<true>(lo);
         hi = wave_reduce_pk<false>(hi);
         if ((tid & 63) == 0) {
-          bb[(wave * L + l) * 2] = lo;
-          bb[(wave * L + l) * 2 + 1] = hi;
+          bbw[(wave * L + l) * 2] = lo;
+          bbw[(wave * L + l) * 2 + 1] = hi;
         }
       }
     }
+  };
+
+  constexpr int BB_HALF = (WIN_BLOCK / 64) * WIN_MAXL * 2;
+  int item = xcd * chunk + slot0;
+  int par = 0;
+  stamp(-1);
+  if (item < item_end) prepass(item, bb);
+  for (; item < item_end; item += nslots) {
+    const unsigned *bbr = bb + par * BB_HALF;
     stamp(0);
-    __syncthreads();                                               // (1) boxes visible
+    __syncthreads();                                               // (A) boxes visible; pool free
     stamp(1);
 
     // ---- windows (identical in every lane; kept in SGPRs) -------------------------------------------------------
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(WIN_BLOCK, NS == 4 ? 3 : 4) void msda_forward_win_k
       for (int ll = 0; ll < L; ++ll) {
         const int l = L - 1 - ll;       // last level first: PCTrans orders levels coarse -> fine and the finest
                                         // level has the largest window and the most samples worth keeping in LDS
-        const LevelWindow w = read_window(bb, L, l);
+        const LevelWindow w = read_window(bbr, L, l);
         wx0[l] = w.x0;
         wy0[l] = w.y0;
         wwid[l] = w.wid;
@@ -432,7 +444,8 @@ __global__ __launch_bounds__(WIN_BLOCK, NS == 4 ? 3 : 4) void msda_forward_win_k
       }
     }
     stamp(5);
-    __syncthreads();                                               // (3) pool / bb free for the next item
+    par ^= 1;
+    if (item + nslots < item_end) prepass(item + nslots, bb + par * BB_HALF);
     stamp(6);
   }
   if constexpr (STAMP) {
@@ -463,7 +476,7 @@ int launch_msda_forward_win(const void *value, const int64_t *shapes, const int6
   const int NS = (ns_env == 1 || ns_env == 2) ? ns_env : 4;
   const int pool_bytes = NS == 1 ? 28 * 1024 : (NS == 2 ? 36 * 1024 : 50 * 1024);
   const int pool_px = pool_bytes / (QL * 16);
-  const size_t lds = (size_t)pool_px * QL * 16 + (WIN_BLOCK / 64) * WIN_MAXL * 2 * sizeof(unsigned);
+  const size_t lds = (size_t)pool_px * QL * 16 + 2 * (WIN_BLOCK / 64) * WIN_MAXL * 2 * sizeof(unsigned);
   const int pyramid = Lq == S ? 1 : 0;
   const int wg_per_cu = NS == 4 ? 3 : 4;
   const dim3 grid(256 * wg_per_cu), block(WIN_BLOCK);
