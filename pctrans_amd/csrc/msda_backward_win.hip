@@ -461,7 +461,8 @@ __global__ __launch_bounds__(WIN_BLOCK, 2) void msda_backward_win_kernel(
     // of the footprint) once the pool is free again; only what still does not fit takes the direct path
     bool defer[L];
 #pragma unroll
-    for (int l = 0; l < L; ++l) defer[l] = fixed_ok && !in_lds[l] && wsize[l] > 0;
+    for (int l = 0; l < L; ++l)
+      defer[l] = fixed_ok && !in_lds[l] && wsize[l] > 0 && wsize[l] <= 2 * NS * (pool_px - 2);   // else hopeless
 
     // ---- main pass: per slot, every lane walks the samples of its query, geometry from the owner lane by DPP ----
 #pragma unroll 1
