@@ -26,6 +26,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The FPN / input-projection convolutions stay on MIOpen (north_star).  On a fresh box MIOpen's default hybrid find
+# mode settles on slow solvers for them (measured: 110.8 ms/step against 87.3 ms/step with the measured-best ones),
+# so ask for a full find: it runs once per convolution shape, inside the untimed pre-warm steps below.
+os.environ.setdefault("MIOPEN_FIND_MODE", "1")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
