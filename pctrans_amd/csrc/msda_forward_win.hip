@@ -484,8 +484,8 @@ int launch_msda_forward_win(const void *value, const int64_t *shapes, const int6
   const float *lc = static_cast<const float *>(loc), *at = static_cast<const float *>(attn);
   ST *o = static_cast<ST *>(out);
   if constexpr (sizeof(ST) == 4) {
-    if (g_stamp_buffer && !ref && L == 4 && NS == 2) {   // diagnostic build: per-phase cycle stamps (tools/stamp_msda.py)
-      hipLaunchKernelGGL((msda_forward_win_kernel<T, 16, 4, 4, 2, false, true>), grid, block, lds, stream, v, shapes,
+    if (g_stamp_buffer && !ref && L == 4 && NS == 4) {   // diagnostic build: per-phase cycle stamps (tools/stamp_msda.py)
+      hipLaunchKernelGGL((msda_forward_win_kernel<T, 16, 4, 4, 4, false, true>), grid, block, lds, stream, v, shapes,
                          starts, lc, at, N, S, M, Lq, pyramid, pool_px, o, ref, ref_batch_stride, g_stamp_buffer);
       return (int)hipGetLastError();
     }

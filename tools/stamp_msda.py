@@ -28,8 +28,9 @@ MSDA.ms_deform_attn_forward(v, sh, st, loc, w, 128)
 torch.cuda.synchronize()
 lib.pct_debug_set_stamp_buffer(None)
 t = buf.view(1024, 8).double().cpu()
-names = ["prepass(bbox)", "barrier1", "prefetch+windows", "staging", "barrier2", "gather", "store+barrier3", "-"]
+names = ["first prepass", "barrier A (boxes, pool free)", "windows", "staging issue", "barrier B (staged)", "gather+store",
+         "next item's prepass", "-"]
 tot = t.sum(1).mean().item()
 print("dist=%s N=%d  mean cycles per WG %.0f" % (dist, N, tot))
 for i, n in enumerate(names[:7]):
-    print("  %-18s %6.1f %%   %10.0f cyc/WG" % (n, 100 * t[:, i].mean().item() / tot, t[:, i].mean().item()))
+    print("  %-30s %6.1f %%   %10.0f cyc/WG" % (n, 100 * t[:, i].mean().item() / tot, t[:, i].mean().item()))
