@@ -36,7 +36,7 @@ namespace pct {
 // location = ref[q, l] + offset / (W_l, H_l) and weight = softmax over the record's L*P logits itself
 // (ops/modules/ms_deform_attn.py:100-109), as msda_forward_dpp.hip does.
 template <typename T, int D, int L, int P, int NS, bool FUSED, bool STAMP = false>
-__global__ __launch_bounds__(WIN_BLOCK, NS == 4 ? 3 : 4) void msda_forward_win_kernel(   // NS=4: 50 KB LDS -> 3 WG/CU
+__global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_forward_win_kernel(   // 50 KB LDS -> 3 WG/CU
     const typename Traits<T>::store_t *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn, const int N,
     const int S, const int M, const int Lq, const int pyramid, const int pool_px,
@@ -468,17 +468,18 @@ int launch_msda_forward_win(const void *value, const int64_t *shapes, const int6
   constexpr int VEC = 16 / (int)sizeof(ST);
   if ((((uintptr_t)value | (uintptr_t)out) & 15u) || (((uintptr_t)loc) & 7u) || (((uintptr_t)attn) & 3u)) return -100;
   if (ref && (((uintptr_t)ref) & 7u)) return -100;
-  if (D != 16 || P != 4 || L < 3 || L > 5) return -100;
+  if (D != 16 || (P != 4 && P != 8) || L < 3 || L > 5) return -100;
   if ((long long)N * Lq * M < 32768) return -100;                  // too small to fill a persistent grid
   if ((long long)N * ((long long)S + 64 * L) * M >= 0x7fffffffLL) return -100;   // item counter is 32-bit
   constexpr int QL = 16 / VEC;
   static const int ns_env = [] { const char *e = getenv("PCT_WIN_NS"); return e ? atoi(e) : 4; }();
-  const int NS = (ns_env == 1 || ns_env == 2) ? ns_env : 4;
-  const int pool_bytes = NS == 1 ? 28 * 1024 : (NS == 2 ? 36 * 1024 : 50 * 1024);
+  // P = 8 (config 5): twice the points per lane -> 2 slots per lane, but still the 50 KB pool / 3 workgroups per CU
+  const int NS = P == 8 ? (sizeof(ST) == 2 ? 1 : 2) : ((ns_env == 1 || ns_env == 2) ? ns_env : 4);   // 16-bit: 128 queries per slot
+  const int pool_bytes = P == 8 ? 50 * 1024 : (NS == 1 ? 28 * 1024 : (NS == 2 ? 36 * 1024 : 50 * 1024));
   const int pool_px = pool_bytes / (QL * 16);
   const size_t lds = (size_t)pool_px * QL * 16 + 2 * (WIN_BLOCK / 64) * WIN_MAXL * 2 * sizeof(unsigned);
   const int pyramid = Lq == S ? 1 : 0;
-  const int wg_per_cu = NS == 4 ? 3 : 4;
+  const int wg_per_cu = (NS == 4 || P == 8) ? 3 : 4;
   const dim3 grid(256 * wg_per_cu), block(WIN_BLOCK);
   const ST *v = static_cast<const ST *>(value);
   const float *lc = static_cast<const float *>(loc), *at = static_cast<const float *>(attn);
@@ -490,9 +491,23 @@ int launch_msda_forward_win(const void *value, const int64_t *shapes, const int6
       return (int)hipGetLastError();
     }
   }
-#define PCT_WIN(L_, NS_, FU_)                                                                                      \
-  hipLaunchKernelGGL((msda_forward_win_kernel<T, 16, L_, 4, NS_, FU_>), grid, block, lds, stream, v, shapes, starts, \
+#define PCT_WINP(L_, P_, NS_, FU_)                                                                                    \
+  hipLaunchKernelGGL((msda_forward_win_kernel<T, 16, L_, P_, NS_, FU_>), grid, block, lds, stream, v, shapes, starts, \
                      lc, at, N, S, M, Lq, pyramid, pool_px, o, ref, ref_batch_stride, nullptr)
+#define PCT_WIN(L_, NS_, FU_) PCT_WINP(L_, 4, NS_, FU_)
+  if (P == 8) {
+    constexpr int NS8 = sizeof(ST) == 2 ? 1 : 2;
+    if (ref) {
+      if (L == 3) PCT_WINP(3, 8, NS8, true);
+      else if (L == 4) PCT_WINP(4, 8, NS8, true);
+      else PCT_WINP(5, 8, NS8, true);
+    } else {
+      if (L == 3) PCT_WINP(3, 8, NS8, false);
+      else if (L == 4) PCT_WINP(4, 8, NS8, false);
+      else PCT_WINP(5, 8, NS8, false);
+    }
+    return (int)hipGetLastError();
+  }
 #define PCT_WIN_L(NS_, FU_)                 \
   if (L == 3) PCT_WIN(3, NS_, FU_);         \
   else if (L == 4) PCT_WIN(4, NS_, FU_);    \
@@ -508,6 +523,7 @@ int launch_msda_forward_win(const void *value, const int64_t *shapes, const int6
   }
 #undef PCT_WIN_L
 #undef PCT_WIN
+#undef PCT_WINP
   return (int)hipGetLastError();
 }
 

@@ -272,10 +272,12 @@ def test_windowed_kernel_tile_local_inf_does_not_leak(MSDA):
     np.testing.assert_allclose(got[fin], want[fin], rtol=0, atol=1e-4)
 
 
+@pytest.mark.parametrize("P,shapes", [(4, [(16, 16), (32, 32), (64, 64), (128, 128)]),
+                                      (8, [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64)])])      # P = 8, L = 5: config 5
 @pytest.mark.parametrize("tdt,eps", [(torch.float16, 2.0 ** -11), (torch.bfloat16, 2.0 ** -8)])
-def test_windowed_kernel_16bit(MSDA, tdt, eps):
-    c = make_case(seed=72, N=2, M=8, D=16, Lq=21760, P=4, shapes=[(16, 16), (32, 32), (64, 64), (128, 128)],
-                  model_like=True)
+def test_windowed_kernel_16bit(MSDA, tdt, eps, P, shapes):
+    Lq = sum(h * w for h, w in shapes)
+    c = make_case(seed=72, N=2, M=8, D=16, Lq=Lq, P=P, shapes=shapes, model_like=True)
     v16 = torch.from_numpy(c["value"]).to(tdt)
     want = orc.forward(v16.float().numpy(), c["shapes"], c["starts"], c["loc"], c["attn"])
     got = MSDA.ms_deform_attn_forward(v16.cuda(), dev(c["shapes"]), dev(c["starts"]), dev(c["loc"]), dev(c["attn"]),
