@@ -483,6 +483,8 @@ def test_fullsize_backward_adjoint_identities(MSDA):
     out = MSDA.ms_deform_attn_forward(v, sh, st, loc, attn, 64)
     gv, gl, ga = MSDA.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64)
     lhs = (go.double() * out.double()).sum().item()
-    assert abs((gv.double() * v.double()).sum().item() - lhs) <= 1e-5 * abs(lhs) + 1e-2
-    assert abs((ga.double() * attn.double()).sum().item() - lhs) <= 1e-5 * abs(lhs) + 1e-2
+    # rounding noise of a 22M-term dot product scales with the sum of magnitudes, not with the (random-sign) sum
+    tol = 1e-7 * (go.double().abs() * out.double().abs()).sum().item()
+    assert abs((gv.double() * v.double()).sum().item() - lhs) <= tol
+    assert abs((ga.double() * attn.double()).sum().item() - lhs) <= tol
     assert torch.isfinite(gl).all()
