@@ -190,6 +190,10 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
         }
       }
     }
+    // The boxes must have reached the LDS before this wave arrives at barrier (A).  With the pre-pass in the loop
+    // latch hipcc (ROCm 7.2) emits that s_barrier at the loop header WITHOUT the s_waitcnt lgkmcnt(0) it places before
+    // every other barrier, and 1 launch in ~8 read stale boxes (caught by the adjoint test): wait explicitly.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
 
   constexpr int BB_HALF = (WIN_BLOCK / 64) * WIN_MAXL * 2;
