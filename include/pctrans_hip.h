@@ -142,6 +142,23 @@ PCT_API int pct_dynamic_mask_head_forward_mfma(const float *mask_feat, const flo
 PCT_API int pct_add_layernorm_f32(const float *x, const float *y, const float *gamma, const float *beta, float eps,
                                   long long rows, int cols, float *out, void *stream);
 
+/* ---- skinny fp32 projection GEMMs (K = 128) on the fp32 MFMA path ------------------------------------------------
+ * pct_linear_k128_f32:  y[rows, n] = act(x[rows, 128] . w[n, 128]^T + bias[n]),  act 0 = none, 1 = ReLU.
+ *   Replaces nn.Linear for MSDeformAttn's value_proj / sampling_offsets / attention_weights
+ *   (ops/modules/ms_deform_attn.py:64-67, 96-103) and the encoder FFN's linear1 + ReLU
+ *   (pixel_decoder/msdeformattn.py:103-106, 126).
+ * pct_linear_k128_add_layernorm_f32:  out[rows, 128] = LayerNorm(residual + x . w[128, 128]^T + bias) * gamma + beta.
+ *   Replaces output_proj followed by `src = src + dropout1(src2); src = norm1(src)` (ops/modules/ms_deform_attn.py:123,
+ *   pixel_decoder/msdeformattn.py:116-119), eval mode (dropout = identity).
+ * All matrices fp32 row-major; ldx / ldy / ldr = row strides in elements (>= 128 / n / 128); x, w 16-byte aligned with
+ * ldx % 4 == 0; n % 32 == 0 (else PCT_ERR_UNSUPPORTED); bias may be NULL in the first form; out may alias residual. */
+PCT_API int pct_linear_k128_f32(const float *x, long long ldx, const float *w, const float *bias, long long rows, int n,
+                                int act, float *y, long long ldy, void *stream);
+PCT_API int pct_linear_k128_add_layernorm_f32(const float *x, long long ldx, const float *w, const float *bias,
+                                              const float *residual, long long ldr, const float *gamma,
+                                              const float *beta, float eps, long long rows, float *out,
+                                              long long ldo, void *stream);
+
 /* ---- fused masked attention core (MFMA, bf16 operands, fp32 accumulate) ---------------------------------------
  * Replaces q*scale -> bmm(q,k^T) -> masked_fill(-inf) -> softmax -> bmm(p,v) of multi_head_attention_forward
  * (transformer_decoder/attention.py:271-387) for the PCTrans decoder under bf16 autocast.

@@ -12,6 +12,9 @@ namespace pct {
 template <typename T>
 int launch_msda_forward(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
                         int, int, int, int, void *, hipStream_t);
+int launch_linear_k128(const float *x, long long ldx, const float *w, const float *bias, long long rows, int n, int epi,
+                       float *y, long long ldy, const float *residual, long long ldr, const float *gamma,
+                       const float *beta, float eps, hipStream_t stream);
 template <typename A>
 int launch_msda_backward(const void *, const int64_t *, const int64_t *, const void *, const void *, const void *,
                          int, int, int, int, int, int, int, void *, void *, void *, hipStream_t);
@@ -229,6 +232,30 @@ int pct_add_layernorm_f32(const float *x, const float *y, const float *gamma, co
   if (!x || !gamma || !beta || !out) return PCT_ERR_BAD_ARG;
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15u) return PCT_ERR_ALIGNMENT;
   return pct::launch_add_layernorm(x, y, gamma, beta, eps, rows, cols, out, static_cast<hipStream_t>(stream));
+}
+
+int pct_linear_k128_f32(const float *x, long long ldx, const float *w, const float *bias, long long rows, int n,
+                        int act, float *y, long long ldy, void *stream)
+{
+  if (rows < 0 || n <= 0 || ldx < 128 || ldy < n || (act != 0 && act != 1)) return PCT_ERR_BAD_ARG;
+  if (rows == 0) return PCT_OK;
+  if (!x || !w || !y) return PCT_ERR_BAD_ARG;
+  if (n % 32) return PCT_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x | (uintptr_t)w) & 15u) || (ldx & 3)) return PCT_ERR_ALIGNMENT;
+  return pct::launch_linear_k128(x, ldx, w, bias, rows, n, act, y, ldy, nullptr, 0, nullptr, nullptr, 0.f,
+                                 static_cast<hipStream_t>(stream));
+}
+
+int pct_linear_k128_add_layernorm_f32(const float *x, long long ldx, const float *w, const float *bias,
+                                      const float *residual, long long ldr, const float *gamma, const float *beta,
+                                      float eps, long long rows, float *out, long long ldo, void *stream)
+{
+  if (rows < 0 || ldx < 128 || ldr < 128 || ldo < 128) return PCT_ERR_BAD_ARG;
+  if (rows == 0) return PCT_OK;
+  if (!x || !w || !residual || !gamma || !beta || !out) return PCT_ERR_BAD_ARG;
+  if ((((uintptr_t)x | (uintptr_t)w) & 15u) || (ldx & 3)) return PCT_ERR_ALIGNMENT;
+  return pct::launch_linear_k128(x, ldx, w, bias, rows, 128, 2, out, ldo, residual, ldr, gamma, beta, eps,
+                                 static_cast<hipStream_t>(stream));
 }
 
 int pct_masked_attention_bf16(const void *q, const void *k, const void *vT, const unsigned char *mask, int batch,

@@ -40,6 +40,65 @@ def linear_relu(x, linear):
     return out.view(*x.shape[:-1], linear.out_features)
 
 
+def linear_k128_supported(x, weight, bias=None):
+    """fp32 device tensors, in_features == 128, out_features % 32 == 0, forward only, outside autocast."""
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.is_cuda):
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        return False
+    if torch.is_autocast_enabled():
+        return False
+    return (x.shape[-1] == 128 and weight.shape[1] == 128 and weight.shape[0] % 32 == 0 and x.numel() >= 128 * 4096
+            and weight.is_contiguous() and (bias is None or bias.is_contiguous()))
+
+
+def _rows_2d(x):
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    return x2
+
+
+def linear_k128(x, weight, bias=None, relu=False):
+    """act(x @ weight.T + bias) for in_features = 128 on the hand-written fp32 MFMA kernel (csrc/linear_k128.hip)."""
+    x2 = _rows_2d(x)
+    rows, n = x2.shape[0], weight.shape[0]
+    out = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().pct_linear_k128_f32(
+            x2.data_ptr(), x2.stride(0), weight.data_ptr(), bias.data_ptr() if bias is not None else None, rows, n,
+            1 if relu else 0, out.data_ptr(), n, torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "linear_k128")
+    return out.view(*x.shape[:-1], n)
+
+
+def linear(x, lin, relu=False):
+    """[relu](lin(x)) for an nn.Linear: the K = 128 MFMA kernel when it applies, else the library GEMM (with the
+    bias + ReLU in its epilogue)."""
+    if linear_k128_supported(x, lin.weight, lin.bias):
+        return linear_k128(x, lin.weight, lin.bias, relu=relu)
+    return linear_relu(x, lin) if relu else lin(x)
+
+
+def linear_add_layer_norm(x, linear, residual, norm):
+    """norm(residual + linear(x)) for a 128 -> 128 Linear and LayerNorm(128): one kernel, one pass over the rows."""
+    if not (linear_k128_supported(x, linear.weight, linear.bias) and linear.out_features == 128
+            and residual.dtype == torch.float32 and residual.shape[:-1] == x.shape[:-1] and residual.shape[-1] == 128
+            and norm.weight is not None and norm.bias is not None and tuple(norm.normalized_shape) == (128,)):
+        return add_layer_norm(residual, linear(x), norm)
+    x2, r2 = _rows_2d(x), _rows_2d(residual)
+    rows = x2.shape[0]
+    out = torch.empty((rows, 128), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().pct_linear_k128_add_layernorm_f32(
+            x2.data_ptr(), x2.stride(0), linear.weight.data_ptr(),
+            linear.bias.data_ptr() if linear.bias is not None else None, r2.data_ptr(), r2.stride(0),
+            norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps), rows, out.data_ptr(), 128,
+            torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "linear_add_layer_norm")
+    return out.view(residual.shape)
+
+
 def masked_attention_supported(q, k, v, num_heads, attn_mask, key_padding_mask, dropout_p, training, need_weights):
     """bf16 device tensors, head dims (32|16, 16), boolean mask shared by the heads (or none), forward only."""
     if not (q.is_cuda and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16):

@@ -69,17 +69,19 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
 
     def forward_ffn(self, src):
         if self._eval_fused(src):
-            src2 = self.linear2(fused_ops.linear_relu(src, self.linear1))
+            src2 = self.linear2(fused_ops.linear(src, self.linear1, relu=True))
             return fused_ops.add_layer_norm(src, src2, self.norm2)
         src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
         return self.norm2(src + self.dropout3(src2))
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
-        src2 = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
-                              level_start_index, padding_mask)
         if self._eval_fused(src):
-            src = fused_ops.add_layer_norm(src, src2, self.norm1)
+            # output_proj + residual + norm1 in one kernel
+            src = self.self_attn.forward_add_norm(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
+                                                  level_start_index, padding_mask, src, self.norm1)
         else:
+            src2 = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
+                                  level_start_index, padding_mask)
             src = self.norm1(src + self.dropout1(src2))
         return self.forward_ffn(src)
 

@@ -18,6 +18,7 @@ from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
 from .... import MultiScaleDeformableAttention as MSDA
+from .... import fused_ops
 from ..functions import MSDeformAttnFunction, ms_deform_attn_core_pytorch
 
 _ALLOW_CPU_REFERENCE = False
@@ -84,8 +85,21 @@ class MSDeformAttn(nn.Module):
                 and self.d_model // self.n_heads == 16 and self.n_points in (4, 8) and self.n_heads <= 16
                 and value.numel() * 4 < 2 ** 31 - 1)
 
+    def forward_add_norm(self, query, reference_points, input_flatten, input_spatial_shapes,
+                         input_level_start_index, input_padding_mask, residual, norm):
+        """norm(residual + self(query, ...)) -- the encoder layer's `src = norm1(src + dropout1(src2))` in eval mode
+        (pixel_decoder/msdeformattn.py:116-119) with output_proj, the residual add and the LayerNorm in one kernel when
+        the fp32 forward-only path applies."""
+        return self.forward(query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                            input_padding_mask, _residual=residual, _norm=norm)
+
+    def _project_out(self, output, residual, norm):
+        if norm is None:
+            return fused_ops.linear(output, self.output_proj)
+        return fused_ops.linear_add_layer_norm(output, self.output_proj, residual, norm)
+
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
-                input_padding_mask=None):
+                input_padding_mask=None, _residual=None, _norm=None):
         """query (N, Lq, C); reference_points (N, Lq, n_levels, 2|4) in [0,1]; input_flatten (N, sum H_l*W_l, C);
         input_spatial_shapes (n_levels, 2) as (H_l, W_l); input_level_start_index (n_levels,);
         input_padding_mask (N, sum H_l*W_l) True = padding.  Returns (N, Lq, C)."""
@@ -93,18 +107,20 @@ class MSDeformAttn(nn.Module):
         N, Len_in, _ = input_flatten.shape
         assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
 
-        value = self.value_proj(input_flatten)
+        value = fused_ops.linear(input_flatten, self.value_proj)     # K = 128 MFMA kernel when forward-only fp32
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
         if self._can_fuse(value, query, reference_points):
             # one launch: softmax + location math + sampling (no sampling_locations tensor, no softmax output)
-            offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
-            logits = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
+            offsets = fused_ops.linear(query, self.sampling_offsets).view(
+                N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+            logits = fused_ops.linear(query, self.attention_weights).view(
+                N, Len_q, self.n_heads, self.n_levels * self.n_points)
             output = MSDA.ms_deform_attn_fused_forward(
                 value.contiguous(), input_spatial_shapes, input_level_start_index, reference_points,
                 offsets.contiguous(), logits.contiguous())
-            return self.output_proj(output)
+            return self._project_out(output, _residual, _norm)
         sampling_offsets = self.sampling_offsets(query).view(
             N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
         attention_weights = self.attention_weights(query).view(
@@ -130,4 +146,6 @@ class MSDeformAttn(nn.Module):
         else:
             raise RuntimeError("Not implemented on the CPU")
         output = self.output_proj(output)
+        if _norm is not None:
+            output = _norm(_residual + output)
         return output

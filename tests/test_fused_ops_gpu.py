@@ -5,6 +5,8 @@ from torch import nn
 
 pytestmark = pytest.mark.gpu
 
+from pctrans_amd import fused_ops  # noqa: E402
+
 
 @pytest.mark.parametrize("rows,cols", [(348160 // 8, 128), (1600, 128), (7, 128), (1000, 256), (33, 64)])
 @pytest.mark.parametrize("with_y", [True, False])
@@ -119,3 +121,54 @@ def test_attention_core_dispatches_to_mfma_kernel_and_matches_torch_path():
     with torch.no_grad():
         c, _ = attention_core(q, k, v, 8, attn_mask=mask2)
     assert torch.isnan(c[5, 1]).all() and torch.isfinite(c[4, 1]).all()
+
+
+@pytest.mark.parametrize("rows,n,relu,bias", [(4096, 128, False, True), (5000, 256, True, True), (33, 128, False, False),
+                                              (21760 * 2, 384, False, True), (4097, 1024, True, True), (5376, 192, False, True),
+                                              (5376, 96, False, True), (3000, 640, False, True)])
+def test_linear_k128_matches_fp64_matmul(rows, n, relu, bias):
+    """Hand-written fp32 MFMA GEMM (k-permuted operands, accumulator-layout epilogue) against an fp64 product; the
+    tolerance is the fp32 accumulation noise of a 128-term dot product."""
+    g = torch.Generator(device="cuda").manual_seed(rows + n)
+    x = torch.randn(rows, 128, device="cuda", generator=g)
+    w = torch.randn(n, 128, device="cuda", generator=g) * 0.1
+    b = torch.randn(n, device="cuda", generator=g) if bias else None
+    got = fused_ops.linear_k128(x, w, b, relu=relu)
+    want = x.double() @ w.double().t()
+    if bias:
+        want = want + b.double()
+    if relu:
+        want = want.relu()
+    assert got.shape == (rows, n)
+    torch.testing.assert_close(got.double(), want, rtol=0, atol=2e-5)
+    # and it is at least as accurate as the library GEMM it replaces
+    lib = torch.nn.functional.linear(x, w, b)
+    if relu:
+        lib = lib.relu()
+    assert (got.double() - want).abs().max() <= 2.0 * (lib.double() - want).abs().max() + 1e-6
+
+
+def test_linear_k128_strided_rows_and_view_shapes():
+    x_full = torch.randn(3, 1000, 256, device="cuda")
+    x = x_full[..., :128]                                   # row stride 256, still 16-byte aligned
+    w = torch.randn(128, 128, device="cuda") * 0.1
+    got = fused_ops.linear_k128(x, w)
+    assert got.shape == (3, 1000, 128)
+    torch.testing.assert_close(got, torch.nn.functional.linear(x, w), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("rows", [21760, 4099])
+def test_linear_add_layer_norm_equals_unfused(rows):
+    torch.manual_seed(rows)
+    lin = torch.nn.Linear(128, 128).cuda()
+    norm = torch.nn.LayerNorm(128).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+        x = torch.randn(2, rows, 128, device="cuda")
+        res = torch.randn(2, rows, 128, device="cuda") * 3 + 1.5
+        got = fused_ops.linear_add_layer_norm(x, lin, res, norm)
+        want = torch.nn.functional.layer_norm((res.double() + x.double() @ lin.weight.double().t() + lin.bias.double()),
+                                              (128,), norm.weight.double(), norm.bias.double(), norm.eps)
+    assert got.shape == res.shape
+    torch.testing.assert_close(got.double(), want, rtol=0, atol=2e-5)
