@@ -143,7 +143,9 @@ PCT_API int pct_add_layernorm_f32(const float *x, const float *y, const float *g
                                   long long rows, int cols, float *out, void *stream);
 
 /* ---- skinny fp32 projection GEMMs (K = 128) on the fp32 MFMA path ------------------------------------------------
- * pct_linear_k128_f32:  y[rows, n] = act(x[rows, 128] . w[n, 128]^T + bias[n]),  act 0 = none, 1 = ReLU.
+ * pct_linear_k128_f32:  y[rows, n] = act((x + x_add)[rows, 128] . w[n, 128]^T + bias[n]),  act 0 = none, 1 = ReLU;
+ *   x_add may be NULL (it is the encoder's `with_pos_embed(src, pos)`, pixel_decoder/msdeformattn.py:112-114); it has
+ *   add_period >= 32 rows and repeats: row i of x pairs with row i % add_period (pos is the same for every image).
  *   Replaces nn.Linear for MSDeformAttn's value_proj / sampling_offsets / attention_weights
  *   (ops/modules/ms_deform_attn.py:64-67, 96-103) and the encoder FFN's linear1 + ReLU
  *   (pixel_decoder/msdeformattn.py:103-106, 126).
@@ -152,8 +154,9 @@ PCT_API int pct_add_layernorm_f32(const float *x, const float *y, const float *g
  *   pixel_decoder/msdeformattn.py:116-119), eval mode (dropout = identity).
  * All matrices fp32 row-major; ldx / ldy / ldr = row strides in elements (>= 128 / n / 128); x, w 16-byte aligned with
  * ldx % 4 == 0; n % 32 == 0 (else PCT_ERR_UNSUPPORTED); bias may be NULL in the first form; out may alias residual. */
-PCT_API int pct_linear_k128_f32(const float *x, long long ldx, const float *w, const float *bias, long long rows, int n,
-                                int act, float *y, long long ldy, void *stream);
+PCT_API int pct_linear_k128_f32(const float *x, long long ldx, const float *x_add, long long ld_add, long long add_period,
+                                const float *w, const float *bias, long long rows, int n, int act, float *y,
+                                long long ldy, void *stream);
 PCT_API int pct_linear_k128_add_layernorm_f32(const float *x, long long ldx, const float *w, const float *bias,
                                               const float *residual, long long ldr, const float *gamma,
                                               const float *beta, float eps, long long rows, float *out,

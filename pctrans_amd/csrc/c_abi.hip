@@ -12,7 +12,9 @@ namespace pct {
 template <typename T>
 int launch_msda_forward(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
                         int, int, int, int, void *, hipStream_t);
-int launch_linear_k128(const float *x, long long ldx, const float *w, const float *bias, long long rows, int n, int epi,
+int launch_linear_k128(const float *x, long long ldx, const float *x2, long long ldx2, long long x2_period, const float *w,
+                       const float *bias,
+                       long long rows, int n, int epi,
                        float *y, long long ldy, const float *residual, long long ldr, const float *gamma,
                        const float *beta, float eps, hipStream_t stream);
 template <typename A>
@@ -234,15 +236,18 @@ int pct_add_layernorm_f32(const float *x, const float *y, const float *gamma, co
   return pct::launch_add_layernorm(x, y, gamma, beta, eps, rows, cols, out, static_cast<hipStream_t>(stream));
 }
 
-int pct_linear_k128_f32(const float *x, long long ldx, const float *w, const float *bias, long long rows, int n,
-                        int act, float *y, long long ldy, void *stream)
+int pct_linear_k128_f32(const float *x, long long ldx, const float *x_add, long long ld_add, long long add_period,
+                        const float *w, const float *bias, long long rows, int n, int act, float *y, long long ldy,
+                        void *stream)
 {
   if (rows < 0 || n <= 0 || ldx < 128 || ldy < n || (act != 0 && act != 1)) return PCT_ERR_BAD_ARG;
+  if (x_add && (ld_add < 128 || (ld_add & 3) || ((uintptr_t)x_add & 15u))) return PCT_ERR_ALIGNMENT;
+  if (x_add && (add_period < 32 || add_period * ld_add * 4 > 0x7fffffffLL)) return PCT_ERR_BAD_ARG;
   if (rows == 0) return PCT_OK;
   if (!x || !w || !y) return PCT_ERR_BAD_ARG;
   if (n % 32) return PCT_ERR_UNSUPPORTED;
   if ((((uintptr_t)x | (uintptr_t)w) & 15u) || (ldx & 3)) return PCT_ERR_ALIGNMENT;
-  return pct::launch_linear_k128(x, ldx, w, bias, rows, n, act, y, ldy, nullptr, 0, nullptr, nullptr, 0.f,
+  return pct::launch_linear_k128(x, ldx, x_add, ld_add, add_period, w, bias, rows, n, act, y, ldy, nullptr, 0, nullptr, nullptr, 0.f,
                                  static_cast<hipStream_t>(stream));
 }
 
@@ -254,7 +259,7 @@ int pct_linear_k128_add_layernorm_f32(const float *x, long long ldx, const float
   if (rows == 0) return PCT_OK;
   if (!x || !w || !residual || !gamma || !beta || !out) return PCT_ERR_BAD_ARG;
   if ((((uintptr_t)x | (uintptr_t)w) & 15u) || (ldx & 3)) return PCT_ERR_ALIGNMENT;
-  return pct::launch_linear_k128(x, ldx, w, bias, rows, 128, 2, out, ldo, residual, ldr, gamma, beta, eps,
+  return pct::launch_linear_k128(x, ldx, nullptr, 0, 0, w, bias, rows, 128, 2, out, ldo, residual, ldr, gamma, beta, eps,
                                  static_cast<hipStream_t>(stream));
 }
 

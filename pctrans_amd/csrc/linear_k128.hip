@@ -55,10 +55,10 @@ __device__ __forceinline__ float lin_half_sum(float v)
 
 constexpr int LIN_LDA = 132;                      // LDS row stride of the A image (floats)
 
-template <int EPI>
+template <int EPI, bool HAS_X2>
 __global__ __launch_bounds__(LIN_BLOCK, 2) void linear_k128_kernel(
-    const float *__restrict__ X, const long long ldx, const float *__restrict__ W, const float *__restrict__ bias,
-    const long long M, const int N, float *__restrict__ Y, const long long ldy, const float *__restrict__ R,
+    const float *__restrict__ X, const long long ldx, const float *__restrict__ X2, const long long ldx2,
+    const int x2_period, const float *__restrict__ W, const float *__restrict__ bias, const long long M, const int N, float *__restrict__ Y, const long long ldy, const float *__restrict__ R,
     const long long ldr, const float *__restrict__ gamma, const float *__restrict__ beta, const float eps)
 {
   __shared__ __attribute__((aligned(16))) float abuf[2][32 * LIN_LDA];
@@ -106,30 +106,47 @@ __global__ __launch_bounds__(LIN_BLOCK, 2) void linear_k128_kernel(
   const int g_voff = (int)((tid >> 5) * ldx * 4) + 16 * (tid & 31);
   const int g_step = (int)(8 * ldx * 4);
   const int s_off = (tid >> 5) * LIN_LDA + 4 * (tid & 31);
-  auto fetch = [&](const long long tile, lin_i32x4 (&g)[4]) {
+  // HAS_X2: the A operand is X + X2 (the encoder's `query = src + pos`), added on the way into LDS.  X2 has
+  // x2_period rows and repeats (pos is the same for every image of the batch: row i of X pairs with row i % period).
+  const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(HAS_X2 ? X2 : X), 0,
+                                                     (int)((long long)x2_period * ldx2 * 4), 0x00020000);
+  auto fetch = [&](const long long tile, lin_i32x4 (&g)[4], lin_i32x4 (&g2)[4]) {
     const auto rs = tile_rsrc(X, ldx, tile);
 #pragma unroll
     for (int q = 0; q < 4; ++q) g[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, g_voff, q * g_step, 0);
-  };
-  auto stash = [&](float *dst, const lin_i32x4 (&g)[4]) {
+    if constexpr (HAS_X2) {
+      const int base = (int)((tile * 32) % x2_period);              // uniform
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<lin_i32x4 *>(dst + s_off + q * 8 * LIN_LDA) = g[q];
+      for (int q = 0; q < 4; ++q) {
+        int row = base + (tid >> 5) + 8 * q;
+        row = row >= x2_period ? row - x2_period : row;
+        g2[q] = __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)(row * ldx2 * 4) + 16 * (tid & 31), 0, 0);
+      }
+    }
+  };
+  auto stash = [&](float *dst, const lin_i32x4 (&g)[4], const lin_i32x4 (&g2)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      lin_f32x4 v = __builtin_bit_cast(lin_f32x4, g[q]);
+      if constexpr (HAS_X2) v += __builtin_bit_cast(lin_f32x4, g2[q]);
+      *reinterpret_cast<lin_f32x4 *>(dst + s_off + q * 8 * LIN_LDA) = v;
+    }
   };
 
   const int y_voff = (int)((4 * h * ldy + col) * 4);
   const int r_voff = (int)((4 * h * ldr + col) * 4);
   const int a_off = r * LIN_LDA + 4 * h;
 
-  lin_i32x4 g[4];
+  lin_i32x4 g[4], g2[4] = {};
   long long tile = blockIdx.x;
   if (tile < ntiles) {
-    fetch(tile, g);
-    stash(abuf[0], g);
+    fetch(tile, g, g2);
+    stash(abuf[0], g, g2);
   }
   __syncthreads();
   for (int buf = 0; tile < ntiles; tile += gridDim.x, buf ^= 1) {
     const long long nxt = tile + gridDim.x;
-    if (nxt < ntiles) fetch(nxt, g);                              // in flight during the MFMAs
+    if (nxt < ntiles) fetch(nxt, g, g2);                          // in flight during the MFMAs
 
     if (active || EPI == LIN_EPI_RES_LN) {
     // two accumulator chains: consecutive MFMAs never wait on each other's result
@@ -193,13 +210,15 @@ __global__ __launch_bounds__(LIN_BLOCK, 2) void linear_k128_kernel(
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v[j]), ry, y_voff, (int)((8 * (j / 4) + (j % 4)) * ldy * 4), 0);
     }
 
-    if (nxt < ntiles) stash(abuf[buf ^ 1], g);
+    if (nxt < ntiles) stash(abuf[buf ^ 1], g, g2);
     __syncthreads();                  // next image complete; every wave is done reading this one
   }
 }
 
 // n must be a multiple of 32 (LayerNorm variant: exactly 128); x rows 16-byte aligned
-int launch_linear_k128(const float *x, long long ldx, const float *w, const float *bias, long long rows, int n, int epi,
+int launch_linear_k128(const float *x, long long ldx, const float *x2, long long ldx2, long long x2_period, const float *w,
+                       const float *bias,
+                       long long rows, int n, int epi,
                        float *y, long long ldy, const float *residual, long long ldr, const float *gamma,
                        const float *beta, float eps, hipStream_t stream)
 {
@@ -209,12 +228,19 @@ int launch_linear_k128(const float *x, long long ldx, const float *w, const floa
   const long long cap = 256LL * wgs;                               // persistent: `wgs` workgroups per CU (LDS allows 4)
   const unsigned gx = (unsigned)(ntiles < cap ? ntiles : cap);
   const dim3 grid(gx, (unsigned)((n + 127) / 128)), block(LIN_BLOCK);
-#define PCT_LIN(EPI_)                                                                                          \
-  hipLaunchKernelGGL((linear_k128_kernel<EPI_>), grid, block, 0, stream, x, ldx, w, bias, rows, n, y, ldy, residual, \
-                     ldr, gamma, beta, eps)
-  if (epi == LIN_EPI_BIAS) PCT_LIN(LIN_EPI_BIAS);
-  else if (epi == LIN_EPI_BIAS_RELU) PCT_LIN(LIN_EPI_BIAS_RELU);
-  else PCT_LIN(LIN_EPI_RES_LN);
+#define PCT_LIN(EPI_, X2_)                                                                                          \
+  hipLaunchKernelGGL((linear_k128_kernel<EPI_, X2_>), grid, block, 0, stream, x, ldx, x2, ldx2, (int)x2_period, w, bias, rows, n, \
+                     y, ldy, \
+                     residual, ldr, gamma, beta, eps)
+  if (x2) {
+    if (epi == LIN_EPI_BIAS) PCT_LIN(LIN_EPI_BIAS, true);
+    else if (epi == LIN_EPI_BIAS_RELU) PCT_LIN(LIN_EPI_BIAS_RELU, true);
+    else PCT_LIN(LIN_EPI_RES_LN, true);
+  } else {
+    if (epi == LIN_EPI_BIAS) PCT_LIN(LIN_EPI_BIAS, false);
+    else if (epi == LIN_EPI_BIAS_RELU) PCT_LIN(LIN_EPI_BIAS_RELU, false);
+    else PCT_LIN(LIN_EPI_RES_LN, false);
+  }
 #undef PCT_LIN
   return (int)hipGetLastError();
 }

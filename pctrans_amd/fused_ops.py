@@ -59,24 +59,44 @@ def _rows_2d(x):
     return x2
 
 
-def linear_k128(x, weight, bias=None, relu=False):
-    """act(x @ weight.T + bias) for in_features = 128 on the hand-written fp32 MFMA kernel (csrc/linear_k128.hip)."""
+def _x_add_ok(x, x_add):
+    """x_add: same trailing shape as x, fp32, and either the same batch or batch 1 (broadcast over the images)."""
+    return (x_add.is_cuda and x_add.dtype == torch.float32 and x_add.dim() == x.dim() and x.dim() >= 2
+            and x_add.shape[1:] == x.shape[1:] and x_add.shape[0] in (1, x.shape[0])
+            and x.numel() // x.shape[0] // 128 >= 32)
+
+
+def linear_k128(x, weight, bias=None, relu=False, x_add=None):
+    """act((x + x_add) @ weight.T + bias) for in_features = 128 on the hand-written fp32 MFMA kernel
+    (csrc/linear_k128.hip); x_add (shape of x, or batch 1 = shared by the images, or None) is summed on the way into
+    the kernel's LDS tiles."""
     x2 = _rows_2d(x)
     rows, n = x2.shape[0], weight.shape[0]
+    a2, period = None, 0
+    if x_add is not None:
+        if x_add.shape[0] != 1 and x_add.stride(0) == 0:          # an expanded batch-1 tensor
+            x_add = x_add[:1]
+        a2 = _rows_2d(x_add)
+        period = a2.shape[0]
     out = torch.empty((rows, n), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         rc = _lib.lib().pct_linear_k128_f32(
-            x2.data_ptr(), x2.stride(0), weight.data_ptr(), bias.data_ptr() if bias is not None else None, rows, n,
+            x2.data_ptr(), x2.stride(0), a2.data_ptr() if a2 is not None else None,
+            a2.stride(0) if a2 is not None else 0, period, weight.data_ptr(),
+            bias.data_ptr() if bias is not None else None, rows, n,
             1 if relu else 0, out.data_ptr(), n, torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(rc, "linear_k128")
     return out.view(*x.shape[:-1], n)
 
 
-def linear(x, lin, relu=False):
-    """[relu](lin(x)) for an nn.Linear: the K = 128 MFMA kernel when it applies, else the library GEMM (with the
-    bias + ReLU in its epilogue)."""
-    if linear_k128_supported(x, lin.weight, lin.bias):
-        return linear_k128(x, lin.weight, lin.bias, relu=relu)
+def linear(x, lin, relu=False, x_add=None):
+    """[relu](lin(x [+ x_add])) for an nn.Linear: the K = 128 MFMA kernel when it applies, else the library GEMM (with
+    the bias + ReLU in its epilogue)."""
+    if linear_k128_supported(x, lin.weight, lin.bias) and (
+            x_add is None or _x_add_ok(x, x_add)):
+        return linear_k128(x, lin.weight, lin.bias, relu=relu, x_add=x_add)
+    if x_add is not None:
+        x = x + x_add
     return linear_relu(x, lin) if relu else lin(x)
 
 

@@ -77,8 +77,8 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         if self._eval_fused(src):
             # output_proj + residual + norm1 in one kernel
-            src = self.self_attn.forward_add_norm(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
-                                                  level_start_index, padding_mask, src, self.norm1)
+            src = self.self_attn.forward_add_norm(src, reference_points, src, spatial_shapes, level_start_index,
+                                                  padding_mask, src, self.norm1, query_pos=pos)
         else:
             src2 = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
                                   level_start_index, padding_mask)
@@ -165,6 +165,9 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         shapes = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
         bs = srcs[0].shape[0]
         src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        # the sine table is the same for every image (PositionEmbeddingSine returns an expanded view when there is no
+        # padding mask): keep one [1, S, C] copy; every consumer broadcasts it over the batch
+        pos_embeds = [p[:1] if (p.shape[0] > 1 and p.stride(0) == 0) else p for p in pos_embeds]
         lvl_pos_embed_flatten = torch.cat(
             [p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)
              for lvl, p in enumerate(pos_embeds)], 1)

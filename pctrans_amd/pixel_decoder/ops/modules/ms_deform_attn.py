@@ -86,12 +86,13 @@ class MSDeformAttn(nn.Module):
                 and value.numel() * 4 < 2 ** 31 - 1)
 
     def forward_add_norm(self, query, reference_points, input_flatten, input_spatial_shapes,
-                         input_level_start_index, input_padding_mask, residual, norm):
-        """norm(residual + self(query, ...)) -- the encoder layer's `src = norm1(src + dropout1(src2))` in eval mode
-        (pixel_decoder/msdeformattn.py:116-119) with output_proj, the residual add and the LayerNorm in one kernel when
-        the fp32 forward-only path applies."""
+                         input_level_start_index, input_padding_mask, residual, norm, query_pos=None):
+        """norm(residual + self(query + query_pos, ...)) -- the encoder layer's `src2 = self_attn(with_pos_embed(src,
+        pos), ...); src = norm1(src + dropout1(src2))` in eval mode (pixel_decoder/msdeformattn.py:112-119): when the
+        fp32 forward-only path applies, `query + query_pos` is formed inside the projection kernels and output_proj,
+        the residual add and the LayerNorm are one kernel."""
         return self.forward(query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
-                            input_padding_mask, _residual=residual, _norm=norm)
+                            input_padding_mask, _residual=residual, _norm=norm, _query_pos=query_pos)
 
     def _project_out(self, output, residual, norm):
         if norm is None:
@@ -99,7 +100,7 @@ class MSDeformAttn(nn.Module):
         return fused_ops.linear_add_layer_norm(output, self.output_proj, residual, norm)
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
-                input_padding_mask=None, _residual=None, _norm=None):
+                input_padding_mask=None, _residual=None, _norm=None, _query_pos=None):
         """query (N, Lq, C); reference_points (N, Lq, n_levels, 2|4) in [0,1]; input_flatten (N, sum H_l*W_l, C);
         input_spatial_shapes (n_levels, 2) as (H_l, W_l); input_level_start_index (n_levels,);
         input_padding_mask (N, sum H_l*W_l) True = padding.  Returns (N, Lq, C)."""
@@ -113,14 +114,16 @@ class MSDeformAttn(nn.Module):
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
         if self._can_fuse(value, query, reference_points):
             # one launch: softmax + location math + sampling (no sampling_locations tensor, no softmax output)
-            offsets = fused_ops.linear(query, self.sampling_offsets).view(
+            offsets = fused_ops.linear(query, self.sampling_offsets, x_add=_query_pos).view(
                 N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
-            logits = fused_ops.linear(query, self.attention_weights).view(
+            logits = fused_ops.linear(query, self.attention_weights, x_add=_query_pos).view(
                 N, Len_q, self.n_heads, self.n_levels * self.n_points)
             output = MSDA.ms_deform_attn_fused_forward(
                 value.contiguous(), input_spatial_shapes, input_level_start_index, reference_points,
                 offsets.contiguous(), logits.contiguous())
             return self._project_out(output, _residual, _norm)
+        if _query_pos is not None:
+            query = query + _query_pos
         sampling_offsets = self.sampling_offsets(query).view(
             N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
         attention_weights = self.attention_weights(query).view(

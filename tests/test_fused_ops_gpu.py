@@ -148,6 +148,21 @@ def test_linear_k128_matches_fp64_matmul(rows, n, relu, bias):
     assert (got.double() - want).abs().max() <= 2.0 * (lib.double() - want).abs().max() + 1e-6
 
 
+@pytest.mark.parametrize("S,shared", [(5000, False), (5376, True), (7481, True), (33, True)])
+def test_linear_k128_adds_the_positional_operand_on_the_fly(S, shared):
+    """x_add = the encoder's positional term: per image, or one [1, S, 128] tensor shared by the batch (the kernel
+    wraps its row index; S need not be a multiple of the 32-row tile)."""
+    x = torch.randn(3, S, 128, device="cuda")
+    pos = torch.randn(1 if shared else 3, S, 128, device="cuda")
+    lin = torch.nn.Linear(128, 256).cuda()
+    with torch.no_grad():
+        got = fused_ops.linear_k128(x, lin.weight, lin.bias, x_add=pos)
+        got_expanded = fused_ops.linear_k128(x, lin.weight, lin.bias, x_add=pos.expand(3, -1, -1))
+        want = ((x.double() + pos.double()) @ lin.weight.double().t() + lin.bias.double())
+    torch.testing.assert_close(got.double(), want, rtol=0, atol=3e-5)
+    torch.testing.assert_close(got_expanded, got, rtol=0, atol=0)
+
+
 def test_linear_k128_strided_rows_and_view_shapes():
     x_full = torch.randn(3, 1000, 256, device="cuda")
     x = x_full[..., :128]                                   # row stride 256, still 16-byte aligned

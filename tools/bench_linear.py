@@ -40,3 +40,9 @@ with torch.no_grad():
     t_lib = timed(lambda: fused_ops.add_layer_norm(res, torch.nn.functional.linear(x, lin.weight, lin.bias), norm))
     t_own = timed(lambda: fused_ops.linear_add_layer_norm(x, lin, res, norm))
     print("output_proj + residual + LayerNorm: library GEMM + add_layernorm %.3f ms   fused %.3f ms" % (t_lib, t_own))
+    pos = torch.randn(rows, 128, device="cuda")
+    for n in (128, 256):
+        lin = torch.nn.Linear(128, n).cuda()
+        t_sep = timed(lambda: fused_ops.linear_k128(x + pos, lin.weight, lin.bias))
+        t_fused = timed(lambda: fused_ops.linear_k128(x, lin.weight, lin.bias, x_add=pos))
+        print("n=%4d (x + pos): add kernel + linear_k128 %.3f ms   x_add operand %.3f ms" % (n, t_sep, t_fused))
