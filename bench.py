@@ -26,9 +26,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# The FPN / input-projection convolutions stay on MIOpen (north_star).  On a fresh box MIOpen's default hybrid find
-# mode settles on slow solvers for them (measured: 110.8 ms/step against 87.3 ms/step with the measured-best ones),
-# so ask for a full find: it runs once per convolution shape, inside the untimed pre-warm steps below.
+# With 4 encoder levels every convolution of the head is 1x1 and runs as a strided-batched GEMM (layers.Conv2d); with the
+# shipped 3-level yaml the FPN's 3x3 convolutions stay on MIOpen (north_star).  On a fresh box MIOpen's default hybrid
+# find mode can settle on slow solvers (measured: 110.8 ms/step against 87.3 ms/step with the measured-best ones when
+# the 1x1 convolutions still went through it), so ask for a full find: it runs once per shape in the untimed pre-warm.
 os.environ.setdefault("MIOPEN_FIND_MODE", "1")
 
 import torch  # noqa: E402

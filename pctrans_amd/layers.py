@@ -75,8 +75,25 @@ class Conv2d(nn.Conv2d):
         self.norm = norm
         self.activation = activation
 
+    def _pointwise(self, x):
+        return (x.is_cuda and x.dim() == 4 and self.kernel_size == (1, 1) and self.stride == (1, 1)
+                and self.padding == (0, 0) and self.dilation == (1, 1) and self.groups == 1
+                and self.padding_mode == "zeros" and x.is_contiguous())
+
     def forward(self, x):
-        x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if self._pointwise(x):
+            # a 1x1 convolution on NCHW data is W[Cout,Cin] @ x[n][Cin,HW]: one strided-batched GEMM, no layout
+            # transposes and no dependence on MIOpen's per-process solver search (autocast treats it like conv2d)
+            n, c, h, w = x.shape
+            wm = self.weight.view(1, self.out_channels, c).expand(n, -1, -1)
+            x3 = x.view(n, c, h * w)
+            if self.bias is not None:
+                y = torch.baddbmm(self.bias.view(1, -1, 1), wm, x3)
+            else:
+                y = torch.bmm(wm, x3)
+            x = y.view(n, self.out_channels, h, w)
+        else:
+            x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
         if self.norm is not None:
             x = self.norm(x)
         if self.activation is not None:
@@ -89,3 +106,37 @@ def c2_xavier_fill(module):
     nn.init.kaiming_uniform_(module.weight, a=1)
     if module.bias is not None:
         nn.init.constant_(module.bias, 0)
+
+
+class CachedLinear(nn.Linear):
+    """nn.Linear with the same parameters / state-dict keys; under CUDA autocast in forward-only use it keeps
+    low-precision copies of weight and bias instead of re-casting them on every forward (autocast's own cache lives only
+    for one autocast region: ~330 cast launches per decoder forward), and can apply ReLU in the GEMM epilogue.  The copies
+    are keyed on the parameters' version counters and storage, so optimizer steps, `load_state_dict` and `.to()` refresh
+    them.  Anything else (fp32, CPU, autograd) is plain `nn.Linear`."""
+
+    _lp_cache = None
+
+    def _low_precision(self, dtype):
+        w, b = self.weight, self.bias
+        key = (dtype, w._version, w.data_ptr(), -1 if b is None else b._version, 0 if b is None else b.data_ptr())
+        c = self._lp_cache
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                c = (key, w.detach().to(dtype), None if b is None else b.detach().to(dtype))
+            self._lp_cache = c
+        return c[1], c[2]
+
+    def forward(self, x, relu=False):
+        if (x.is_cuda and torch.is_autocast_enabled("cuda")
+                and not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))):
+            dtype = torch.get_autocast_dtype("cuda")
+            w, b = self._low_precision(dtype)
+            x = x if x.dtype == dtype else x.to(dtype)
+            if relu and b is not None:
+                x2 = x.reshape(-1, x.shape[-1])
+                return torch._addmm_activation(b, x2, w.t(), use_gelu=False).view(*x.shape[:-1], w.shape[0])
+            y = F.linear(x, w, b)
+            return F.relu(y) if relu else y
+        y = super().forward(x)
+        return F.relu(y) if relu else y

@@ -209,7 +209,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         chans = transformer_in_channels[::-1] if self.transformer_num_feature_levels > 1 \
             else [transformer_in_channels[-1]]
         self.input_proj = nn.ModuleList(
-            nn.Sequential(nn.Conv2d(c, conv_dim, kernel_size=1), nn.GroupNorm(32, conv_dim)) for c in chans)
+            nn.Sequential(Conv2d(c, conv_dim, kernel_size=1), nn.GroupNorm(32, conv_dim)) for c in chans)
         for proj in self.input_proj:
             nn.init.xavier_uniform_(proj[0].weight, gain=1)
             nn.init.constant_(proj[0].bias, 0)

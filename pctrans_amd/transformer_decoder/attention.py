@@ -19,6 +19,7 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from .. import fused_ops
+from ..layers import CachedLinear
 
 
 def attention_core(q: Tensor, k: Tensor, v: Tensor, num_heads: int, attn_mask: Optional[Tensor] = None,
@@ -89,7 +90,7 @@ class MultiheadAttention(nn.Module):
         self.dropout = dropout
         self.head_dim = embed_dim // num_heads
         assert self.head_dim * num_heads == self.embed_dim, "embed_dim must be divisible by num_heads"
-        self.out_proj = nn.Linear(self.vdim, self.vdim)
+        self.out_proj = CachedLinear(self.vdim, self.vdim)
         self._reset_parameters()
 
     def _reset_parameters(self):

@@ -33,7 +33,7 @@ from torch.nn import functional as F
 
 from .. import dynamic_mask_head as dmh
 from .. import fused_ops
-from ..layers import Conv2d, c2_xavier_fill, get_norm
+from ..layers import CachedLinear, Conv2d, c2_xavier_fill, get_norm
 from .attention import MultiheadAttention
 from .position_encoding import PositionEmbeddingSine
 
@@ -92,11 +92,11 @@ def _xavier_all(module):
 class SelfAttentionLayer(nn.Module):
     def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
         super().__init__()
-        self.sa_qcontent_proj = nn.Linear(d_model, d_model)
-        self.sa_qpos_proj = nn.Linear(d_model, d_model)
-        self.sa_kcontent_proj = nn.Linear(d_model, d_model)
-        self.sa_kpos_proj = nn.Linear(d_model, d_model)
-        self.sa_v_proj = nn.Linear(d_model, d_model)
+        self.sa_qcontent_proj = CachedLinear(d_model, d_model)
+        self.sa_qpos_proj = CachedLinear(d_model, d_model)
+        self.sa_kcontent_proj = CachedLinear(d_model, d_model)
+        self.sa_kpos_proj = CachedLinear(d_model, d_model)
+        self.sa_v_proj = CachedLinear(d_model, d_model)
         self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout, vdim=d_model)
         self.norm1 = nn.LayerNorm(d_model)
         self.dropout1 = nn.Dropout(dropout)
@@ -117,12 +117,12 @@ class SelfAttentionLayer(nn.Module):
 class CrossAttentionLayer(nn.Module):
     def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False, points_num=1):
         super().__init__()
-        self.ca_qcontent_proj = nn.Linear(d_model, d_model)
-        self.ca_qpos_proj = nn.Linear(d_model, d_model)
-        self.ca_kcontent_proj = nn.Linear(d_model, d_model)
-        self.ca_kpos_proj = nn.Linear(d_model, d_model)
-        self.ca_v_proj = nn.Linear(d_model, d_model)
-        self.ca_qpos_sine_proj = nn.Linear(d_model * 2 * points_num, d_model)
+        self.ca_qcontent_proj = CachedLinear(d_model, d_model)
+        self.ca_qpos_proj = CachedLinear(d_model, d_model)
+        self.ca_kcontent_proj = CachedLinear(d_model, d_model)
+        self.ca_kpos_proj = CachedLinear(d_model, d_model)
+        self.ca_v_proj = CachedLinear(d_model, d_model)
+        self.ca_qpos_sine_proj = CachedLinear(d_model * 2 * points_num, d_model)
         self.cross_attn = MultiheadAttention(d_model * 2, nhead, dropout=dropout, vdim=d_model)
         self.nhead = nhead
         self.norm2 = nn.LayerNorm(d_model)
@@ -181,9 +181,9 @@ class CrossAttentionLayer(nn.Module):
 class FFNLayer(nn.Module):
     def __init__(self, d_model, dim_feedforward=2048, dropout=0.0, activation="relu", normalize_before=False):
         super().__init__()
-        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear1 = CachedLinear(d_model, dim_feedforward)
         self.dropout = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.linear2 = CachedLinear(dim_feedforward, d_model)
         self.norm = nn.LayerNorm(d_model)
         self.activation = _get_activation_fn(activation)
         self.normalize_before = normalize_before
@@ -192,12 +192,17 @@ class FFNLayer(nn.Module):
     def with_pos_embed(self, tensor, pos: Optional[Tensor]):
         return tensor if pos is None else tensor + pos
 
+    def _hidden(self, x):
+        if self.activation is F.relu:
+            return self.linear1(x, relu=True)                       # bias + ReLU in the GEMM epilogue under autocast
+        return self.activation(self.linear1(x))
+
     def forward_post(self, tgt):
-        tgt2 = self.linear2(self.dropout(self.activation(self.linear1(tgt))))
+        tgt2 = self.linear2(self.dropout(self._hidden(tgt)))
         return self.norm(tgt + self.dropout(tgt2))
 
     def forward_pre(self, tgt):
-        tgt2 = self.linear2(self.dropout(self.activation(self.linear1(self.norm(tgt)))))
+        tgt2 = self.linear2(self.dropout(self._hidden(self.norm(tgt))))
         return tgt + self.dropout(tgt2)
 
     def forward(self, tgt):
@@ -211,11 +216,11 @@ class MLP(nn.Module):
         super().__init__()
         self.num_layers = num_layers
         h = [hidden_dim] * (num_layers - 1)
-        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+        self.layers = nn.ModuleList(CachedLinear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+            x = layer(x, relu=True) if i < self.num_layers - 1 else layer(x)
         return x
 
 
@@ -345,7 +350,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         self.controller = MLP(hidden_dim, hidden_dim, self.num_gen_params, 3)
         _init_mlp(self.controller)
 
-        self.mask_head = nn.Conv2d(hidden_dim, mask_dim, 1, padding=0)
+        self.mask_head = Conv2d(hidden_dim, mask_dim, 1, padding=0)
         nn.init.kaiming_uniform_(self.mask_head.weight, a=1)
         nn.init.constant_(self.mask_head.bias, 0)
 
@@ -354,7 +359,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             conv_block = conv_with_kaiming_uniform(norm, activation=True)
             self.seg_head = nn.Sequential(conv_block(hidden_dim, hidden_dim, kernel_size=3, stride=1),
                                           conv_block(hidden_dim, hidden_dim, kernel_size=3, stride=1))
-            self.logits = nn.Conv2d(hidden_dim, 1, kernel_size=1, stride=1)
+            self.logits = Conv2d(hidden_dim, 1, kernel_size=1, stride=1)
             prior_prob = 0.01
             nn.init.constant_(self.logits.bias, -math.log((1 - prior_prob) / prior_prob))
 

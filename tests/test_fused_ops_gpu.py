@@ -187,3 +187,51 @@ def test_linear_add_layer_norm_equals_unfused(rows):
                                               (128,), norm.weight.double(), norm.bias.double(), norm.eps)
     assert got.shape == res.shape
     torch.testing.assert_close(got.double(), want, rtol=0, atol=2e-5)
+
+
+def test_cached_linear_equals_autocast_linear_and_follows_weight_updates():
+    from pctrans_amd.layers import CachedLinear
+    torch.manual_seed(3)
+    ref = nn.Linear(128, 64).cuda()
+    lin = CachedLinear(128, 64).cuda()
+    lin.load_state_dict(ref.state_dict())
+    assert sorted(lin.state_dict()) == ["bias", "weight"]
+    x = torch.randn(7, 100, 128, device="cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        assert torch.equal(lin(x), ref(x))
+        assert torch.equal(lin(x, relu=True), torch.relu(ref(x)))
+        ref.weight.mul_(1.5)
+        lin.weight.mul_(1.5)                          # in-place update bumps the version -> the bf16 copy is rebuilt
+        torch.clear_autocast_cache()                  # (autocast itself would keep serving ref's stale bf16 weight)
+        assert torch.equal(lin(x), ref(x))
+        lin.load_state_dict({k: v * 0.5 for k, v in ref.state_dict().items()})
+        ref.load_state_dict(lin.state_dict())
+        torch.clear_autocast_cache()
+        assert torch.equal(lin(x), ref(x))
+    with torch.no_grad():                               # outside autocast: plain fp32 nn.Linear
+        assert torch.equal(lin(x), ref(x))
+    with torch.autocast("cuda", dtype=torch.bfloat16):  # autograd needed: falls back to the differentiable path
+        y = lin(x)
+        assert y.requires_grad
+        y.float().sum().backward()
+        assert lin.weight.grad is not None
+
+
+@pytest.mark.parametrize("cin,cout,hw,bias", [(256, 128, (64, 64), True), (2048, 128, (17, 22), True), (128, 16, (130, 174), False)])
+def test_pointwise_conv2d_is_a_batched_gemm_with_conv_semantics(cin, cout, hw, bias):
+    from pctrans_amd.layers import Conv2d
+    torch.manual_seed(cin)
+    conv = Conv2d(cin, cout, kernel_size=1, bias=bias, norm=nn.GroupNorm(8, cout), activation=torch.relu).cuda()
+    x = torch.randn(3, cin, *hw, device="cuda")
+    with torch.no_grad():
+        got = conv(x)
+        want = torch.relu(conv.norm(torch.nn.functional.conv2d(x.double(), conv.weight.double(),
+                                                              None if conv.bias is None else conv.bias.double()).float()))
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+        # channels-last input takes the library convolution; 3x3 kernels are untouched
+        cl = x.contiguous(memory_format=torch.channels_last)
+        torch.testing.assert_close(conv(cl), want, rtol=1e-4, atol=1e-4)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert conv(x).dtype == torch.float32 or conv(x).dtype == torch.bfloat16
+            y16 = Conv2d(cin, cout, kernel_size=1, bias=bias).cuda()(x)
+            assert y16.dtype == torch.bfloat16          # same autocast policy as conv2d
