@@ -121,10 +121,18 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
     if world > 1:
         assert world == args.gpus, "--gpus must equal WORLD_SIZE"
+    # PCT_BENCH_SHARE_GPU=1 (rehearsal only): several ranks on one card over gloo, to exercise the multi-rank code path
+    # on a 1-GPU box; the judged runs use one GPU per rank over RCCL.
+    share = os.environ.get("PCT_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", init_method="env://", device_id=device)   # nccl == RCCL on ROCm
+        if share:
+            dist.init_process_group("gloo", init_method="env://")
+        else:
+            dist.init_process_group("nccl", init_method="env://", device_id=device)   # nccl == RCCL on ROCm
 
     from pctrans_amd import MultiScaleDeformableAttention as MSDA
     from pctrans_amd import _lib
@@ -159,7 +167,7 @@ def main():
     elapsed = time.perf_counter() - t0
     launches = MSDA.kernel_timing(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
