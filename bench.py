@@ -211,6 +211,20 @@ def main():
                 "share_of_step": (sum(fwd) / (1e3 * elapsed)) if fwd else None,
             },
         }
+        # second hand-written kernel on the path, MFMA-bound: the FFN's linear1 (+ ReLU) on linear_k128.hip
+        ffn1 = [ms for name, ms in launches if name == "linear_k128 n=1024 relu"]
+        if ffn1:
+            rows = args.batch * S
+            ms1 = sum(ffn1) / len(ffn1)
+            tf = 2.0 * rows * 128 * 1024 / (ms1 * 1e-3) / 1e12
+            out["roofline_mfma"] = {
+                "kernel": "pct::linear_k128_kernel<bias+ReLU> (encoder FFN linear1: [%d,128] x [1024,128]^T, fp32, "
+                          "v_mfma_f32_32x32x2_f32)" % rows,
+                "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                "mean_launch_ms": ms1, "launches_timed": len(ffn1), "share_of_step": sum(ffn1) / (1e3 * elapsed),
+                "note": "peak = dense fp32 MFMA rate (256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz); the step's other large "
+                        "GEMM (linear2, K = 1024) runs on hipBLASLt",
+            }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, levels_hw)
             out["cpu_baseline"]["gpu_same_unit"] = args.batch / (mean_ms * 1e-3) if fwd else None

@@ -1,6 +1,8 @@
 """Python entry points of the small fused HIP kernels (C ABI in include/pctrans_hip.h).  Each function has the same
 result as the torch expression in its docstring; callers use them only when no gradient is required (forward-only
 kernels) and the tensors are fp32 on the device, otherwise they evaluate the torch expression."""
+import contextlib
+
 import torch
 from torch.nn import functional as F
 
@@ -79,7 +81,9 @@ def linear_k128(x, weight, bias=None, relu=False, x_add=None):
         a2 = _rows_2d(x_add)
         period = a2.shape[0]
     out = torch.empty((rows, n), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    from . import MultiScaleDeformableAttention as _msda      # shares bench.py's HIP-event timing hook
+    timed = _msda._timed("linear_k128 n=1024 relu", x2) if (n == 1024 and relu) else contextlib.nullcontext()
+    with torch.cuda.device(x.device), timed:
         rc = _lib.lib().pct_linear_k128_f32(
             x2.data_ptr(), x2.stride(0), a2.data_ptr() if a2 is not None else None,
             a2.stride(0) if a2 is not None else 0, period, weight.data_ptr(),
