@@ -131,3 +131,19 @@ def test_head_runs_on_every_baseline_config_shape(name, depth, H, W, Q, levels, 
     scale = max(1.0, float(p32["pred_masks"].abs().max()))
     close = ((p16["pred_masks"].float() - p32["pred_masks"]).abs() <= 0.15 * scale).float().mean()
     assert float(close) > 0.85, float(close)
+
+
+def test_head_forward_is_bitwise_repeatable_at_bench_geometry():
+    """No kernel on the forward-only path uses atomics, so repeated forwards must agree bit for bit -- at the bench's
+    4-level 512x512 geometry, large enough for every windowed / persistent kernel to run multi-item loops (this is the
+    kind of test that exposes a missing wait or barrier)."""
+    head, shapes = _head(4, Q=100)
+    feats = _feats(shapes, 8, 512, 512)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        first, mf0 = head(feats)
+        for _ in range(5):
+            again, mf = head(feats)
+            assert torch.equal(mf0, mf)
+            assert torch.equal(first["pred_masks"], again["pred_masks"])
+            for a, b in zip(first["aux_outputs"], again["aux_outputs"]):
+                assert torch.equal(a["pred_masks"], b["pred_masks"])
