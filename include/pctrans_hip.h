@@ -142,6 +142,16 @@ PCT_API int pct_dynamic_mask_head_forward_mfma(const float *mask_feat, const flo
 PCT_API int pct_add_layernorm_f32(const float *x, const float *y, const float *gamma, const float *beta, float eps,
                                   long long rows, int cols, float *out, void *stream);
 
+/* ---- GroupNorm of an NCHW map written into the encoder's token-major buffer ------------------------------------
+ * out[n, p, c] (at out + n*out_batch_stride + out_offset + p*channels + c) = GroupNorm(x)[n, c, p] * gamma[c] + beta[c].
+ * Replaces nn.GroupNorm(32, conv_dim) of the pixel decoder's input projections + `.flatten(2).transpose(1, 2)` +
+ * `torch.cat(src_flatten, 1)` (pixel_decoder/msdeformattn.py:75-83, 220-224).  x [batch, channels, hw] fp32 16-byte
+ * aligned; channels == 128 and (channels / groups) % 4 == 0, else PCT_ERR_UNSUPPORTED; stats = scratch of
+ * batch*groups*2 floats (receives mean, rstd); strides / offsets in elements. */
+PCT_API int pct_groupnorm_flatten_f32(const float *x, const float *gamma, const float *beta, int batch, int channels,
+                                      int hw, int groups, float eps, float *stats, float *out,
+                                      long long out_batch_stride, long long out_offset, void *stream);
+
 /* ---- skinny fp32 projection GEMMs (K = 128) on the fp32 MFMA path ------------------------------------------------
  * pct_linear_k128_f32:  y[rows, n] = act((x + x_add)[rows, 128] . w[n, 128]^T + bias[n]),  act 0 = none, 1 = ReLU;
  *   x_add may be NULL (it is the encoder's `with_pos_embed(src, pos)`, pixel_decoder/msdeformattn.py:112-114); it has

@@ -25,6 +25,8 @@ int launch_dyn_mask_head_mfma(const float *, const float *, const float *, int, 
                               void *, void *, unsigned char *, hipStream_t);
 int launch_masked_attention(const void *, const void *, const void *, const unsigned char *, int, int, int, int, int,
                             int, float, int, void *, hipStream_t);
+int launch_groupnorm_flatten(const float *, const float *, const float *, int, int, int, int, float, float *, float *,
+                             long long, long long, hipStream_t);
 int launch_add_layernorm(const float *, const float *, const float *, const float *, float, long long, int, float *,
                          hipStream_t);
 template <typename T>
@@ -261,6 +263,19 @@ int pct_linear_k128_add_layernorm_f32(const float *x, long long ldx, const float
   if ((((uintptr_t)x | (uintptr_t)w) & 15u) || (ldx & 3)) return PCT_ERR_ALIGNMENT;
   return pct::launch_linear_k128(x, ldx, nullptr, 0, 0, w, bias, rows, 128, 2, out, ldo, residual, ldr, gamma, beta, eps,
                                  static_cast<hipStream_t>(stream));
+}
+
+int pct_groupnorm_flatten_f32(const float *x, const float *gamma, const float *beta, int batch, int channels, int hw,
+                              int groups, float eps, float *stats, float *out, long long out_batch_stride,
+                              long long out_offset, void *stream)
+{
+  if (batch < 0 || channels <= 0 || hw < 0 || groups <= 0 || out_batch_stride < 0 || out_offset < 0) return PCT_ERR_BAD_ARG;
+  if (batch == 0 || hw == 0) return PCT_OK;
+  if (!x || !gamma || !beta || !stats || !out) return PCT_ERR_BAD_ARG;
+  if (channels != 128 || channels % groups || (channels / groups) % 4) return PCT_ERR_UNSUPPORTED;
+  if ((uintptr_t)x & 15u) return PCT_ERR_ALIGNMENT;
+  return pct::launch_groupnorm_flatten(x, gamma, beta, batch, channels, hw, groups, eps, stats, out, out_batch_stride,
+                                       out_offset, static_cast<hipStream_t>(stream));
 }
 
 int pct_masked_attention_bf16(const void *q, const void *k, const void *vT, const unsigned char *mask, int batch,

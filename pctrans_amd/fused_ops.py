@@ -123,6 +123,26 @@ def linear_add_layer_norm(x, linear, residual, norm):
     return out.view(residual.shape)
 
 
+def groupnorm_flatten_supported(x, gn):
+    """fp32 NCHW device tensor, 128 channels, groups of a multiple of 4 channels, affine, forward only."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 128 and x.is_contiguous()
+            and isinstance(gn, torch.nn.GroupNorm) and gn.num_channels == 128 and (128 // gn.num_groups) % 4 == 0
+            and gn.weight is not None and gn.bias is not None and not torch.is_autocast_enabled()
+            and not (torch.is_grad_enabled() and (x.requires_grad or gn.weight.requires_grad)))
+
+
+def groupnorm_flatten_into(x, gn, out, row_offset):
+    """out[:, row_offset : row_offset + H*W, :] = gn(x).flatten(2).transpose(1, 2)  (out: [N, S, 128] contiguous)."""
+    n, c, h, w = x.shape
+    stats = torch.empty((n * gn.num_groups * 2,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().pct_groupnorm_flatten_f32(
+            x.data_ptr(), gn.weight.data_ptr(), gn.bias.data_ptr(), n, c, h * w, gn.num_groups, float(gn.eps),
+            stats.data_ptr(), out.data_ptr(), out.stride(0), row_offset * c,
+            torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "groupnorm_flatten")
+
+
 def masked_attention_supported(q, k, v, num_heads, attn_mask, key_padding_mask, dropout_p, training, need_weights):
     """bf16 device tensors, head dims (32|16, 16), boolean mask shared by the heads (or none), forward only."""
     if not (q.is_cuda and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16):

@@ -161,10 +161,12 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
             g = self._geom_cache[key] = (ss, starts, ref)
         return g
 
-    def forward(self, srcs, pos_embeds):
+    def forward(self, srcs, pos_embeds, src_flatten=None):
+        """srcs: per-level NCHW maps (or, with `src_flatten` [N, S, C] already filled, anything with their shapes)."""
         shapes = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
         bs = srcs[0].shape[0]
-        src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        if src_flatten is None:
+            src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
         # the sine table is the same for every image (PositionEmbeddingSine returns an expanded view when there is no
         # padding mask): keep one [1, S, C] copy; every consumer broadcasts it over the batch
         pos_embeds = [p[:1] if (p.shape[0] > 1 and p.stride(0) == 0) else p for p in pos_embeds]
@@ -260,12 +262,24 @@ class MSDeformAttnPixelDecoder(nn.Module):
         dev_type = next(iter(features.values())).device.type
         with torch.autocast(device_type=dev_type, enabled=False):
             srcs, pos = [], []
-            for idx, f in enumerate(self.transformer_in_features[::-1]):
-                x = features[f].float()
-                srcs.append(self.input_proj[idx](x))
-                pos.append(self.pe_layer(x))
+            xs = [features[f].float() for f in self.transformer_in_features[::-1]]
+            convs = [self.input_proj[idx][0](x) for idx, x in enumerate(xs)]
+            src_flatten = None
+            if all(fused_ops.groupnorm_flatten_supported(c, self.input_proj[idx][1]) for idx, c in enumerate(convs)):
+                # GroupNorm + flatten(2).transpose(1, 2) + the concat over the levels in one pass per level
+                sizes = [c.shape[2] * c.shape[3] for c in convs]
+                src_flatten = torch.empty((convs[0].shape[0], sum(sizes), convs[0].shape[1]), dtype=torch.float32,
+                                          device=convs[0].device)
+                start = 0
+                for idx, c in enumerate(convs):
+                    fused_ops.groupnorm_flatten_into(c, self.input_proj[idx][1], src_flatten, start)
+                    start += sizes[idx]
+                srcs = convs                                       # only their shapes are used from here on
+            else:
+                srcs = [self.input_proj[idx][1](c) for idx, c in enumerate(convs)]
+            pos = [self.pe_layer(x) for x in xs]
 
-            y, spatial_shapes, level_start_index = self.transformer(srcs, pos)
+            y, spatial_shapes, level_start_index = self.transformer(srcs, pos, src_flatten=src_flatten)
             bs = y.shape[0]
             sizes = [int(s.shape[2]) * int(s.shape[3]) for s in srcs]
             out = [z.transpose(1, 2).reshape(bs, -1, s.shape[2], s.shape[3])

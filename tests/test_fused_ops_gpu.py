@@ -235,3 +235,20 @@ def test_pointwise_conv2d_is_a_batched_gemm_with_conv_semantics(cin, cout, hw, b
             assert conv(x).dtype == torch.float32 or conv(x).dtype == torch.bfloat16
             y16 = Conv2d(cin, cout, kernel_size=1, bias=bias).cuda()(x)
             assert y16.dtype == torch.bfloat16          # same autocast policy as conv2d
+
+
+@pytest.mark.parametrize("hw", [(16, 16), (17, 22), (128, 128), (65, 87)])
+def test_groupnorm_flatten_into_equals_groupnorm_then_transpose(hw):
+    torch.manual_seed(hw[0])
+    gn = nn.GroupNorm(32, 128).cuda()
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.uniform_(-0.5, 0.5)
+        x = torch.randn(3, 128, *hw, device="cuda") * 2 + 0.3
+        S = hw[0] * hw[1] + 11
+        out = torch.full((3, S, 128), float("nan"), device="cuda")
+        assert fused_ops.groupnorm_flatten_supported(x, gn)
+        fused_ops.groupnorm_flatten_into(x, gn, out, 7)
+        want = gn(x.double().float()).flatten(2).transpose(1, 2)
+    torch.testing.assert_close(out[:, 7:7 + hw[0] * hw[1]], want, rtol=0, atol=2e-5)
+    assert torch.isnan(out[:, :7]).all() and torch.isnan(out[:, 7 + hw[0] * hw[1]:]).all()    # nothing else touched
