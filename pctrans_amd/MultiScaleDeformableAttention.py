@@ -65,40 +65,7 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-# Optional per-launch timing (bench.py's roofline leg): HIP events recorded on the launch stream right before and
-# after the kernel is enqueued.  Off by default; never synchronises while enabled.
-_TIMING = None
-
-
-def kernel_timing(enable):
-    """kernel_timing(True) starts collecting; kernel_timing(False) stops and returns [(name, milliseconds), ...]."""
-    global _TIMING
-    if enable:
-        _TIMING = []
-        return None
-    rec, _TIMING = _TIMING or [], None
-    out = []
-    for name, e0, e1 in rec:
-        e1.synchronize()
-        out.append((name, e0.elapsed_time(e1)))
-    return out
-
-
-class _timed:
-    def __init__(self, name, t):
-        self.name, self.t = name, t
-
-    def __enter__(self):
-        if _TIMING is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-            self.e0.record(torch.cuda.current_stream(self.t.device))
-
-    def __exit__(self, *exc):
-        if _TIMING is not None and exc[0] is None:
-            self.e1.record(torch.cuda.current_stream(self.t.device))
-            _TIMING.append((self.name, self.e0, self.e1))
-        return False
+from ._timing import kernel_timing, timed as _timed  # noqa: E402,F401  (bench.py's roofline leg)
 
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):

@@ -6,7 +6,7 @@ import contextlib
 import torch
 from torch.nn import functional as F
 
-from . import _lib
+from . import _lib, _timing
 
 
 def _fusable(*tensors):
@@ -81,8 +81,7 @@ def linear_k128(x, weight, bias=None, relu=False, x_add=None):
         a2 = _rows_2d(x_add)
         period = a2.shape[0]
     out = torch.empty((rows, n), dtype=torch.float32, device=x.device)
-    from . import MultiScaleDeformableAttention as _msda      # shares bench.py's HIP-event timing hook
-    timed = _msda._timed("linear_k128 n=1024 relu", x2) if (n == 1024 and relu) else contextlib.nullcontext()
+    timed = _timing.timed("linear_k128 n=1024 relu", x2) if (n == 1024 and relu) else contextlib.nullcontext()
     with torch.cuda.device(x.device), timed:
         rc = _lib.lib().pct_linear_k128_f32(
             x2.data_ptr(), x2.stride(0), a2.data_ptr() if a2 is not None else None,
