@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Golden vectors for the decoder-side math, from the reference's own code.  RUN IN THE DEV CONTAINER ONLY.
+
+`transformer_decoder/mask2former_transformer_decoder.py` of the reference cannot be imported here: its module header
+needs detectron2 / fvcore (absent, un-vendored) and its sibling attention.py does not import on torch >= 2.  The
+functions that carry the decoder's arithmetic, however, depend on nothing but torch:
+
+    gen_sineembed_for_position   :21-39      inverse_sigmoid          :41-45      MLP                 :249-261
+    dynamic_mask_with_coords     :647-697    mask_heads_forward       :699-719    (methods; `self` is only a parameter bag)
+    dice_for                     :917-927    compute_locations        :929-942    parse_dynamic_params :944-979
+    SelfAttentionLayer           :47-103     CrossAttentionLayer      :105-193    FFNLayer            :195-235
+    select_pos_neg_query         :800-860    select_pos_neg_mask      :862-901    (query-contrast bookkeeping)
+
+and the same holds for attention.py once its broken version test (`A or (B and C) < 9`, attention.py:28) is out of the way:
+
+    MultiheadAttention (class)   attention.py:57-177      multi_head_attention_forward   attention.py:180-387
+
+(`_LinearWithBias` is bound to `torch.nn.modules.linear.NonDynamicallyQuantizableLinear`, the symbol the file's own
+else-branch imports on torch >= 1.9.)
+
+Likewise the encoder classes of pixel_decoder/msdeformattn.py (whose header needs detectron2 for the pixel decoder below
+them) run on the reference's own MSDeformAttn module and transformer.py helpers, both importable:
+
+    MSDeformAttnTransformerEncoderOnly :23-89   ...EncoderLayer :92-131   ...Encoder :134-162
+
+This script reads the reference file as text, takes exactly those definitions out of its AST, executes them unmodified
+in a namespace holding torch / nn / F / math (no stand-ins for the missing libraries are written), feeds them seeded
+inputs and stores inputs + outputs as .npz fixtures next to this file.  Nothing of the reference's source is copied
+into the repository; only data is written.
+
+    python tests/golden/make_golden_decoder.py [--ref /root/reference]
+"""
+import argparse
+import ast
+import math
+import os
+import types
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+from torch.nn import functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEC = "connectomics/model/maskformer_block/transformer_decoder/mask2former_transformer_decoder.py"
+ATT = "connectomics/model/maskformer_block/transformer_decoder/attention.py"
+WANTED_FUNCS = {"gen_sineembed_for_position", "inverse_sigmoid", "dice_for", "compute_locations", "parse_dynamic_params",
+                "_get_activation_fn", "select_pos_neg_query", "select_pos_neg_mask"}
+WANTED_CLASSES = {"MLP", "SelfAttentionLayer", "CrossAttentionLayer", "FFNLayer"}
+WANTED_METHODS = {"dynamic_mask_with_coords", "mask_heads_forward"}      # of MultiScaleMaskedTransformerDecoder
+
+
+def load_reference_functions(ref_root, mha_class):
+    import copy
+    import random
+    path = os.path.join(ref_root, DEC)
+    tree = ast.parse(open(path).read(), filename=path)
+    picked = []
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in WANTED_FUNCS:
+            picked.append(node)
+        elif isinstance(node, ast.ClassDef) and node.name in WANTED_CLASSES:
+            picked.append(node)
+        elif isinstance(node, ast.ClassDef) and node.name == "MultiScaleMaskedTransformerDecoder":
+            picked += [n for n in node.body if isinstance(n, ast.FunctionDef) and n.name in WANTED_METHODS]
+    ns = {"torch": torch, "nn": nn, "F": F, "math": math, "Tensor": Tensor, "Optional": Optional,
+          "MultiheadAttention": mha_class, "random": random, "copy": copy}
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    missing = (WANTED_FUNCS | WANTED_CLASSES | WANTED_METHODS) - set(ns)
+    assert not missing, missing
+    return types.SimpleNamespace(**{k: ns[k] for k in WANTED_FUNCS | WANTED_CLASSES | WANTED_METHODS})
+
+
+def load_reference_attention(ref_root):
+    import warnings
+    from typing import List, Tuple
+    from torch.nn.init import constant_, xavier_normal_, xavier_uniform_
+    from torch.nn.modules.linear import NonDynamicallyQuantizableLinear
+    from torch.overrides import handle_torch_function, has_torch_function
+    path = os.path.join(ref_root, ATT)
+    tree = ast.parse(open(path).read(), filename=path)
+    picked = [n for n in tree.body if (isinstance(n, ast.ClassDef) and n.name == "MultiheadAttention")
+              or (isinstance(n, ast.FunctionDef) and n.name == "multi_head_attention_forward")]
+    assert len(picked) == 2
+    ns = {"torch": torch, "nn": nn, "F": F, "math": math, "Tensor": Tensor, "Optional": Optional, "Tuple": Tuple,
+          "List": List, "Module": nn.Module, "warnings": warnings, "constant_": constant_,
+          "xavier_uniform_": xavier_uniform_, "xavier_normal_": xavier_normal_,
+          "_LinearWithBias": NonDynamicallyQuantizableLinear, "has_torch_function": has_torch_function,
+          "handle_torch_function": handle_torch_function, "linear": F.linear, "pad": F.pad, "softmax": F.softmax,
+          "dropout": F.dropout}
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    return ns["MultiheadAttention"]
+
+
+def load_reference_encoder(ref_root):
+    import importlib.util
+    import sys
+    from torch.nn.init import constant_, normal_, uniform_, xavier_uniform_
+    sys.path.insert(0, HERE)
+    import make_golden                                            # the MSDeformAttn loader of the op-level generator
+    _, mod, _ = make_golden.load_reference(ref_root)
+    spec = importlib.util.spec_from_file_location(
+        "ref_transformer", os.path.join(ref_root, os.path.dirname(DEC), "transformer.py"))
+    tr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tr)
+    path = os.path.join(ref_root, "connectomics/model/maskformer_block/pixel_decoder/msdeformattn.py")
+    names = {"MSDeformAttnTransformerEncoderOnly", "MSDeformAttnTransformerEncoderLayer", "MSDeformAttnTransformerEncoder"}
+    tree = ast.parse(open(path).read(), filename=path)
+    picked = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in names]
+    assert len(picked) == 3
+    ns = {"torch": torch, "nn": nn, "F": F, "MSDeformAttn": mod.MSDeformAttn, "_get_clones": tr._get_clones,
+          "_get_activation_fn": tr._get_activation_fn, "xavier_uniform_": xavier_uniform_, "constant_": constant_,
+          "uniform_": uniform_, "normal_": normal_}
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    return ns["MSDeformAttnTransformerEncoderOnly"]
+
+
+def save(name, **arrays):
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **{k: np.asarray(v) for k, v in arrays.items()})
+    print("wrote", name, {k: np.asarray(v).shape for k, v in arrays.items()})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    args = ap.parse_args()
+    RefMHA = load_reference_attention(args.ref)
+    ref = load_reference_functions(args.ref, RefMHA)
+    g = torch.Generator().manual_seed(2024)
+
+    # ---- projection-free multi-head attention (cross-attention geometry of the PCTrans decoder) ---------------------
+    for tag, E, vd, heads, L, S, N in (("ca", 256, 128, 8, 5, 12, 2), ("sa", 128, 128, 8, 6, 6, 3)):
+        torch.manual_seed(11)
+        mha = RefMHA(E, heads, dropout=0.0, vdim=vd).eval()
+        with torch.no_grad():
+            mha.out_proj.weight.normal_(0, 0.1)
+            mha.out_proj.bias.normal_(0, 0.1)
+        q, k, v = torch.randn(L, N, E, generator=g), torch.randn(S, N, E, generator=g), torch.randn(S, N, vd, generator=g)
+        bmask = torch.rand(N, 1, L, S, generator=g) < 0.4
+        bmask[..., 0] = False                                   # no fully masked row
+        bmask = bmask.expand(N, heads, L, S).reshape(N * heads, L, S)
+        fmask = torch.randn(L, S, generator=g)
+        kpm = torch.zeros(N, S, dtype=torch.bool)
+        kpm[:, -2:] = True
+        with torch.no_grad():
+            o0, w0 = mha(q, k, v)
+            o1, w1 = mha(q, k, v, attn_mask=bmask)
+            o2, w2 = mha(q, k, v, attn_mask=fmask, key_padding_mask=kpm)
+        save("dec_attention_" + tag, q=q, k=k, v=v, heads=heads, out_w=mha.out_proj.weight.detach(),
+             out_b=mha.out_proj.bias.detach(), bool_mask=bmask.numpy(), float_mask=fmask, key_padding_mask=kpm.numpy(),
+             out_plain=o0, w_plain=w0, out_bool=o1, w_bool=w1, out_float_kpm=o2, w_float_kpm=w2)
+
+    # ---- sine embedding of reference points + inverse sigmoid -------------------------------------------------------
+    pts2 = torch.rand(7, 3, 2, generator=g)
+    pts4 = torch.rand(5, 2, 4, generator=g)
+    xs = torch.cat([torch.tensor([0.0, 1.0, 1e-4, 1e-3, 0.999, 0.9995, -0.2, 1.3]), torch.rand(24, generator=g)])
+    save("dec_sineembed_inverse_sigmoid", pts2=pts2, emb2=ref.gen_sineembed_for_position(pts2),
+         pts4=pts4, emb4=ref.gen_sineembed_for_position(pts4), emb2_t10=ref.gen_sineembed_for_position(pts2, 10),
+         x=xs, inv=ref.inverse_sigmoid(xs), inv_eps1e5=ref.inverse_sigmoid(xs, 1e-5))
+
+    # ---- MLP (the controller / box-embed shape) --------------------------------------------------------------------
+    torch.manual_seed(7)
+    mlp = ref.MLP(16, 24, 233, 3)
+    x = torch.randn(4, 3, 16, generator=g)
+    sd = {k: v.detach().numpy() for k, v in mlp.state_dict().items()}
+    save("dec_mlp", x=x, y=mlp(x).detach(), **{"sd." + k: v for k, v in sd.items()})
+
+    # ---- dynamic mask head: controller params -> per-query 3-layer conv on [rel coords | mask features] --------------
+    for tag, rel, (H, W), tgt in (("rel", True, (12, 10), (6, 5)), ("norel", False, (9, 11), (5, 6)),
+                                 ("rel_up", True, (8, 8), (16, 16))):
+        N, Q, C, ch, heads, stride = 2, 3, 16, 8, 8, 4
+        cin = C + 2 if rel else C
+        weight_nums, bias_nums = [cin * ch, ch * ch, ch], [ch, ch, 1]
+        bag = types.SimpleNamespace(dynamic_mask_channels=ch, weight_nums=weight_nums, bias_nums=bias_nums,
+                                    num_heads=heads)
+        bag.mask_heads_forward = types.MethodType(ref.mask_heads_forward, bag)
+        feats = torch.randn(N, C, H, W, generator=g)
+        refpts = torch.rand(Q, N, 2, generator=g)
+        params = torch.randn(Q, N, sum(weight_nums) + sum(bias_nums), generator=g) * 0.3
+        logits, amask = ref.dynamic_mask_with_coords(bag, feats, refpts, params, stride, rel, tgt)
+        save("dec_dynamic_mask_head_" + tag, feats=feats, refpts=refpts, params=params, stride=stride,
+             rel_coord=int(rel), target=np.asarray(tgt), heads=heads, logits_x2=logits, attn_mask=amask.numpy(),
+             locations=ref.compute_locations(H, W, stride, "cpu"))
+
+    # ---- the three decoder layer classes (post-norm, eval, dropout 0), position-guided cross-attention ----------------
+    d, heads, Q, N, HW = 64, 8, 6, 2, 20
+    tgt = torch.randn(Q, N, d, generator=g)
+    qpos = torch.randn(Q, N, d, generator=g)
+    mem = torch.randn(HW, N, d, generator=g)
+    pos = torch.randn(HW, N, d, generator=g)
+    qsine = torch.randn(Q, N, 2 * d, generator=g)
+    mmask = torch.rand(N, 1, Q, HW, generator=g) < 0.3
+    mmask[..., 0] = False
+    mmask = mmask.expand(N, heads, Q, HW).reshape(N * heads, Q, HW)
+    torch.manual_seed(21)
+    sa = ref.SelfAttentionLayer(d, heads).eval()
+    ca = ref.CrossAttentionLayer(d, heads).eval()
+    ffn = ref.FFNLayer(d, 2 * d).eval()
+    with torch.no_grad():
+        for m in (sa, ca, ffn):
+            for n_, p_ in m.named_parameters():
+                if p_.dim() == 1:
+                    p_.normal_(0, 0.1) if "norm" not in n_ or "bias" in n_ else p_.uniform_(0.5, 1.5)
+        out = {"sa_out": sa(tgt, query_pos=qpos),
+               "ca_first": ca(tgt, mem, memory_mask=mmask, pos=pos, query_pos=qpos, query_sine_embed=qsine, is_first=True),
+               "ca_later": ca(tgt, mem, memory_mask=mmask, pos=pos, query_pos=qpos, query_sine_embed=qsine, is_first=False),
+               "ca_nomask": ca(tgt, mem, pos=pos, query_pos=qpos, query_sine_embed=qsine, is_first=False),
+               "ffn_out": ffn(tgt)}
+    sds = {}
+    for name, m in (("sa", sa), ("ca", ca), ("ffn", ffn)):
+        sds.update({"sd.%s.%s" % (name, k): v.detach().numpy() for k, v in m.state_dict().items()})
+    save("dec_layers", tgt=tgt, query_pos=qpos, memory=mem, pos=pos, query_sine_embed=qsine, memory_mask=mmask.numpy(),
+         heads=heads, **{k: v.detach() for k, v in out.items()}, **sds)
+
+    # ---- query-contrast selection (deterministic parts: 'contrast' and 'label' of every item) -------------------------
+    Qc, Nc, C = 14, 2, 8
+    query = torch.randn(Qc, Nc, C, generator=g)
+    emb = torch.nn.functional.normalize(torch.randn(Nc, Qc, C, generator=g), dim=2)
+    emb_dist = emb @ emb.transpose(1, 2)
+    masks = torch.randn(Nc, Qc, 6, 5, generator=g) * 2
+    pos_indices = [(torch.tensor([1, 5, 9]), torch.tensor([0, 1, 2])), (torch.tensor([0, 13]), torch.tensor([1, 0]))]
+    items_q = ref.select_pos_neg_query(query, emb_dist, pos_indices)
+    items_m = ref.select_pos_neg_mask(masks, emb_dist, pos_indices)
+    arrays = {"query": query, "emb_dist": emb_dist, "masks": masks, "n_items_q": len(items_q), "n_items_m": len(items_m)}
+    for b, (src, tg) in enumerate(pos_indices):
+        arrays["pos_src_%d" % b], arrays["pos_tgt_%d" % b] = src, tg
+    for i, it in enumerate(items_q):
+        arrays["q%d_contrast" % i], arrays["q%d_label" % i] = it["contrast"], it["label"]
+    for i, it in enumerate(items_m):
+        arrays["m%d_contrast" % i], arrays["m%d_label" % i] = it["contrast"], it["label"]
+    save("dec_query_contrast", **arrays)
+
+    # ---- MSDeformAttn encoder (level embedding, reference points, 2 layers of deformable self-attention + FFN) --------
+    RefEncoder = load_reference_encoder(args.ref)
+    torch.manual_seed(31)
+    enc = RefEncoder(d_model=32, nhead=4, num_encoder_layers=2, dim_feedforward=64, dropout=0.0, activation="relu",
+                     num_feature_levels=3, enc_n_points=4).eval()
+    with torch.no_grad():
+        for layer in enc.encoder.layers:                          # leave the all-zero offset / attention init
+            layer.self_attn.sampling_offsets.weight.normal_(0, 0.05)
+            layer.self_attn.attention_weights.weight.normal_(0, 0.3)
+            for n_, p_ in layer.named_parameters():
+                if p_.dim() == 1 and "norm" in n_:
+                    p_.uniform_(0.5, 1.5) if n_.endswith("weight") else p_.normal_(0, 0.1)
+    shapes = [(3, 4), (6, 8), (12, 16)]
+    srcs = [torch.randn(2, 32, h, w, generator=g) for h, w in shapes]
+    poss = [torch.randn(2, 32, h, w, generator=g) for h, w in shapes]
+    with torch.no_grad():
+        memory, sshapes, starts = enc(srcs, poss)
+    arrays = {"memory": memory, "spatial_shapes": sshapes, "level_start_index": starts}
+    for i in range(3):
+        arrays["src%d" % i], arrays["pos%d" % i] = srcs[i], poss[i]
+    arrays.update({"sd." + k: v.detach().numpy() for k, v in enc.state_dict().items()})
+    save("dec_msdeform_encoder", **arrays)
+
+    # ---- dice_for (pairwise soft dice of the query masks, used by the query-contrast selection) ---------------------
+    m = torch.randn(6, 9, 7, generator=g) * 3
+    save("dec_dice_for", masks=m, dice=ref.dice_for(m))
+
+
+if __name__ == "__main__":
+    main()

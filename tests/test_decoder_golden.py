@@ -1,0 +1,173 @@
+"""CPU: decoder-side math against vectors produced by the reference's OWN functions (tests/golden/make_golden_decoder.py
+executes gen_sineembed_for_position, inverse_sigmoid, MLP, dynamic_mask_with_coords / mask_heads_forward /
+parse_dynamic_params / compute_locations and dice_for straight from the reference file's AST).  fp32, tolerance 1e-5
+relative to scale: the restatements reorder sums (batched matmul instead of N*Q grouped convolutions)."""
+import numpy as np
+import pytest
+import torch
+
+from pctrans_amd.transformer_decoder import mask2former_transformer_decoder as dec
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.fixture()
+def cpu_reference():
+    from pctrans_amd.pixel_decoder.ops.modules import ms_deform_attn as msda_mod
+    prev = msda_mod.allow_cpu_reference(True)
+    yield
+    msda_mod.allow_cpu_reference(prev)
+
+
+def test_sineembed_and_inverse_sigmoid_match_the_reference_functions(golden):
+    g = golden("dec_sineembed_inverse_sigmoid")
+    for pts, emb, temp in ((g["pts2"], g["emb2"], 20), (g["pts4"], g["emb4"], 20), (g["pts2"], g["emb2_t10"], 10)):
+        got = dec.gen_sineembed_for_position(_t(pts), temp)
+        np.testing.assert_allclose(got.numpy(), emb, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(dec.inverse_sigmoid(_t(g["x"])).numpy(), g["inv"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(dec.inverse_sigmoid(_t(g["x"]), 1e-5).numpy(), g["inv_eps1e5"], rtol=1e-6, atol=1e-6)
+
+
+def test_mlp_matches_the_reference_class_and_its_state_dict_keys(golden):
+    g = golden("dec_mlp")
+    mlp = dec.MLP(16, 24, 233, 3)
+    sd = {k[3:]: _t(g[k]) for k in g if k.startswith("sd.")}
+    assert sorted(sd) == sorted(mlp.state_dict())                  # same parameter names as the reference's MLP
+    mlp.load_state_dict(sd)
+    with torch.no_grad():
+        np.testing.assert_allclose(mlp(_t(g["x"])).numpy(), g["y"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["rel", "norel", "rel_up"])
+def test_dynamic_mask_head_batched_formulation_matches_the_reference_method(golden, tag):
+    """`dynamic_mask_with_coords` (:647-697): per-query dynamic convs on [rel coords | mask features], x2 bilinear
+    upsample, and the boolean attention mask at the next level's size (reference: repeated per head)."""
+    g = golden("dec_dynamic_mask_head_" + tag)
+    feats, refpts, params = _t(g["feats"]), _t(g["refpts"]), _t(g["params"])
+    rel, stride, tgt, heads = bool(g["rel_coord"]), int(g["stride"]), tuple(int(v) for v in g["target"]), int(g["heads"])
+    C = feats.shape[1]
+    self = type("Bag", (), {})()
+    self.dynamic_mask_channels, self.controller_layers = 8, 3
+    self.weight_nums = [(C + 2 if rel else C) * 8, 64, 8]
+    self.bias_nums = [8, 8, 1]
+    self.mask_heads_forward_batched = lambda *a: dec.MultiScaleMaskedTransformerDecoder.mask_heads_forward_batched(self, *a)
+    logits, amask = dec.MultiScaleMaskedTransformerDecoder.dynamic_mask_with_coords(
+        self, feats, refpts, params, stride, rel, tgt)
+    scale = max(1.0, float(np.abs(g["logits_x2"]).max()))
+    np.testing.assert_allclose(logits.numpy(), g["logits_x2"], rtol=0, atol=1e-5 * scale)
+    N, Q = feats.shape[0], refpts.shape[0]
+    want_mask = g["attn_mask"].reshape(N, heads, Q, -1)
+    assert (want_mask == want_mask[:, :1]).all()                   # the reference repeats one mask over the heads
+    got_mask = amask.numpy()                                       # [N, 1, Q, hw], broadcast over heads
+    # a logit within float noise of the sigmoid threshold may fall on either side
+    flip = got_mask != want_mask[:, :1]
+    assert flip.mean() < 1e-3
+    np.testing.assert_allclose(dec.compute_locations(feats.shape[2], feats.shape[3], stride, "cpu").numpy(),
+                               g["locations"], rtol=0, atol=0)
+
+
+def test_decoder_dice_for_matches_the_reference_function(golden):
+    from pctrans_amd.transformer_decoder import query_contrast as qc
+    g = golden("dec_dice_for")
+    np.testing.assert_allclose(qc.dice_for(_t(g["masks"])).numpy(), g["dice"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["ca", "sa"])
+def test_multihead_attention_matches_the_reference_class(golden, tag):
+    """Projection-free MultiheadAttention (attention.py:57-387 of the reference, which does not import on torch >= 2):
+    plain, boolean per-head mask, float mask + key padding mask; output and head-averaged weights."""
+    from pctrans_amd.transformer_decoder.attention import MultiheadAttention
+    g = golden("dec_attention_" + tag)
+    q, k, v = _t(g["q"]), _t(g["k"]), _t(g["v"])
+    mha = MultiheadAttention(q.shape[2], int(g["heads"]), dropout=0.0, vdim=v.shape[2]).eval()
+    assert sorted(mha.state_dict()) == ["out_proj.bias", "out_proj.weight"]
+    mha.load_state_dict({"out_proj.weight": _t(g["out_w"]), "out_proj.bias": _t(g["out_b"])})
+    cases = ((dict(), "plain"), (dict(attn_mask=_t(g["bool_mask"])), "bool"),
+             (dict(attn_mask=_t(g["float_mask"]), key_padding_mask=_t(g["key_padding_mask"])), "float_kpm"))
+    with torch.no_grad():
+        for kw, name in cases:
+            out, w = mha(q, k, v, need_weights=True, **kw)
+            np.testing.assert_allclose(out.numpy(), g["out_" + name], rtol=0, atol=2e-5, err_msg=name)
+            np.testing.assert_allclose(w.numpy(), g["w_" + name], rtol=0, atol=2e-6, err_msg=name)
+
+
+def test_decoder_layer_classes_match_the_reference_classes(golden):
+    """SelfAttentionLayer / CrossAttentionLayer (first and later layers, with and without memory mask) / FFNLayer
+    (dec.py:47-235): same state-dict keys, same outputs as the reference's classes run on their own attention."""
+    g = golden("dec_layers")
+    d, heads = g["tgt"].shape[2], int(g["heads"])
+    tgt, qpos, mem, pos, qsine = (_t(g[k]) for k in ("tgt", "query_pos", "memory", "pos", "query_sine_embed"))
+    mmask = _t(g["memory_mask"])
+    layers = {"sa": dec.SelfAttentionLayer(d, heads).eval(), "ca": dec.CrossAttentionLayer(d, heads).eval(),
+              "ffn": dec.FFNLayer(d, 2 * d).eval()}
+    for name, m in layers.items():
+        sd = {k[len("sd.%s." % name):]: _t(g[k]) for k in g if k.startswith("sd.%s." % name)}
+        assert sorted(sd) == sorted(m.state_dict()), name          # the reference's parameter names
+        m.load_state_dict(sd)
+    sa, ca, ffn = layers["sa"], layers["ca"], layers["ffn"]
+    with torch.no_grad():
+        got = {"sa_out": sa(tgt, query_pos=qpos),
+               "ca_first": ca(tgt, mem, memory_mask=mmask, pos=pos, query_pos=qpos, query_sine_embed=qsine, is_first=True),
+               "ca_later": ca(tgt, mem, memory_mask=mmask, pos=pos, query_pos=qpos, query_sine_embed=qsine, is_first=False),
+               "ca_nomask": ca(tgt, mem, pos=pos, query_pos=qpos, query_sine_embed=qsine, is_first=False),
+               "ffn_out": ffn(tgt)}
+    for k, v in got.items():
+        np.testing.assert_allclose(v.numpy(), g[k], rtol=0, atol=2e-5, err_msg=k)
+
+
+def test_query_contrast_selection_matches_the_reference_functions(golden):
+    """select_pos_neg_query / select_pos_neg_mask (dec.py:800-901): same items in the same order, same 'contrast'
+    scores and labels (the reference's randomly sub-sampled 'aux_*' entries are not part of the loss and not compared)."""
+    from pctrans_amd.transformer_decoder import query_contrast as qc
+    g = golden("dec_query_contrast")
+    query, emb_dist, masks = _t(g["query"]), _t(g["emb_dist"]), _t(g["masks"])
+    pos_indices = [(_t(g["pos_src_%d" % b]), _t(g["pos_tgt_%d" % b])) for b in range(query.shape[1])]
+    items_q = qc.select_pos_neg_query(query, emb_dist, pos_indices)
+    items_m = qc.select_pos_neg_mask(masks, emb_dist, pos_indices)
+    assert len(items_q) == int(g["n_items_q"]) and len(items_m) == int(g["n_items_m"])
+    # The reference lists the negatives in the iteration order of a Python set difference (a CPython hash-table detail:
+    # {0, 8, 2} for 14 queries); the restatement lists them ascending.  The loss is a logsumexp over each group, so the
+    # comparison is per group (positives first, then negatives) up to order.
+    for prefix, items in (("q", items_q), ("m", items_m)):
+        for i, it in enumerate(items):
+            want_c, want_l = g["%s%d_contrast" % (prefix, i)].ravel(), g["%s%d_label" % (prefix, i)]
+            got_c, got_l = it["contrast"].numpy().ravel(), it["label"].numpy()
+            np.testing.assert_array_equal(got_l, want_l)
+            for lab in (0, 1):
+                np.testing.assert_allclose(np.sort(got_c[got_l == lab]), np.sort(want_c[want_l == lab]), rtol=1e-5,
+                                           atol=1e-6)
+
+
+def _encoder_from_fixture(g, device):
+    from pctrans_amd.pixel_decoder.msdeformattn import MSDeformAttnTransformerEncoderOnly
+    enc = MSDeformAttnTransformerEncoderOnly(d_model=32, nhead=4, num_encoder_layers=2, dim_feedforward=64, dropout=0.0,
+                                             activation="relu", num_feature_levels=3, enc_n_points=4).eval()
+    sd = {k[3:]: _t(g[k]) for k in g if k.startswith("sd.")}
+    assert sorted(sd) == sorted(enc.state_dict())                  # the reference's parameter names
+    enc.load_state_dict(sd)
+    srcs = [_t(g["src%d" % i]).to(device) for i in range(3)]
+    poss = [_t(g["pos%d" % i]).to(device) for i in range(3)]
+    return enc.to(device), srcs, poss
+
+
+def test_msdeform_encoder_matches_the_reference_classes(golden, cpu_reference):
+    """MSDeformAttnTransformerEncoderOnly / EncoderLayer / Encoder (msdeformattn.py:23-162 of the reference, run on the
+    reference's own MSDeformAttn module): level embedding, flattening order, reference points, two layers."""
+    g = golden("dec_msdeform_encoder")
+    enc, srcs, poss = _encoder_from_fixture(g, "cpu")
+    with torch.no_grad():
+        memory, shapes, starts = enc(srcs, poss)
+    np.testing.assert_array_equal(shapes.numpy(), g["spatial_shapes"])
+    np.testing.assert_array_equal(starts.numpy(), g["level_start_index"])
+    np.testing.assert_allclose(memory.numpy(), g["memory"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_msdeform_encoder_on_the_hip_kernels_matches_the_reference_classes(golden):
+    g = golden("dec_msdeform_encoder")
+    enc, srcs, poss = _encoder_from_fixture(g, "cuda")
+    with torch.no_grad():
+        memory, _, _ = enc(srcs, poss)
+    np.testing.assert_allclose(memory.cpu().numpy(), g["memory"], rtol=0, atol=1e-4)

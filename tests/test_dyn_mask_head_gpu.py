@@ -131,3 +131,22 @@ def test_resize_kernel_exact_x2_path_is_bitwise_torch_bf16_interpolate():
     assert float(close) > 0.995
     # borders use lambda = 0 / replicated indices: corners must equal their source logit's neighbourhood mix, finite
     assert torch.isfinite(up.float()).all()
+
+
+@pytest.mark.parametrize("tag", ["rel", "norel", "rel_up"])
+def test_fused_mask_head_kernel_matches_the_reference_method_fixture(golden, tag):
+    """The HIP kernel (through the C ABI) against vectors produced by the reference's own dynamic_mask_with_coords /
+    mask_heads_forward / parse_dynamic_params (tests/golden/make_golden_decoder.py)."""
+    import numpy as np
+    from pctrans_amd import dynamic_mask_head as dmh
+    g = golden("dec_dynamic_mask_head_" + tag)
+    feats = torch.from_numpy(g["feats"]).cuda()
+    ref_xy = torch.from_numpy(g["refpts"]).transpose(0, 1).contiguous().cuda()         # [N, Q, 2]
+    params = torch.from_numpy(g["params"]).transpose(0, 1).contiguous().cuda()         # [N, Q, G]
+    rel, stride, tgt, heads = bool(g["rel_coord"]), int(g["stride"]), tuple(int(v) for v in g["target"]), int(g["heads"])
+    up, amask = dmh.dynamic_mask_head_forward(feats, ref_xy, params, stride, rel, tgt)
+    scale = max(1.0, float(np.abs(g["logits_x2"]).max()))
+    np.testing.assert_allclose(up.cpu().numpy(), g["logits_x2"], rtol=0, atol=1e-4 * scale)
+    N, Q = feats.shape[0], ref_xy.shape[1]
+    want = g["attn_mask"].reshape(N, heads, Q, -1)[:, 0]
+    assert (amask.cpu().numpy() != want).mean() < 1e-3            # logits at the sigmoid threshold may fall either side

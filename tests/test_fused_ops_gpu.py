@@ -252,3 +252,23 @@ def test_groupnorm_flatten_into_equals_groupnorm_then_transpose(hw):
         want = gn(x.double().float()).flatten(2).transpose(1, 2)
     torch.testing.assert_close(out[:, 7:7 + hw[0] * hw[1]], want, rtol=0, atol=2e-5)
     assert torch.isnan(out[:, :7]).all() and torch.isnan(out[:, 7 + hw[0] * hw[1]:]).all()    # nothing else touched
+
+
+@pytest.mark.parametrize("tag,masked", [("ca", True), ("ca", False), ("sa", False)])
+def test_mfma_attention_kernel_against_the_reference_class_fixture(golden, tag, masked):
+    """The bf16 MFMA attention kernel (C ABI) followed by out_proj, against the fp32 output of the reference's own
+    MultiheadAttention (tests/golden/make_golden_decoder.py); tolerance = bf16 operand rounding."""
+    import numpy as np
+    g = golden("dec_attention_" + tag)
+    heads = int(g["heads"])
+    q, k, v = (torch.from_numpy(g[n]).cuda() for n in ("q", "k", "v"))
+    if q.shape[2] // heads not in (16, 32) or v.shape[2] // heads != 16:
+        pytest.skip("head geometry outside the MFMA kernel")
+    L, N, S = q.shape[0], q.shape[1], k.shape[0]
+    mask = None
+    if masked:
+        mask = torch.from_numpy(g["bool_mask"]).view(N, heads, L, S)[:, :1].contiguous().cuda()
+    core = fused_ops.masked_attention(q.bfloat16(), k.bfloat16(), v.bfloat16(), heads, mask).float()
+    out = core @ torch.from_numpy(g["out_w"]).cuda().t() + torch.from_numpy(g["out_b"]).cuda()
+    want = g["out_bool" if masked else "out_plain"]
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=3e-2 * max(1.0, float(np.abs(want).max())))
