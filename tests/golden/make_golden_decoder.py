@@ -23,6 +23,11 @@ them) run on the reference's own MSDeformAttn module and transformer.py helpers,
 
     MSDeformAttnTransformerEncoderOnly :23-89   ...EncoderLayer :92-131   ...Encoder :134-162
 
+Finally the whole `MultiScaleMaskedTransformerDecoder` (:267-768) is run in eval mode (targets=None) for a configuration
+that never touches its detectron2 names (in_channels == hidden_dim, no forced input projection, no semantic head): the
+class is taken from the AST with the `@configurable` decorator of `__init__` (it only adds the from_config calling
+convention) and the class's registry decorator not applied, and constructed with explicit keyword arguments.
+
 This script reads the reference file as text, takes exactly those definitions out of its AST, executes them unmodified
 in a namespace holding torch / nn / F / math (no stand-ins for the missing libraries are written), feeds them seeded
 inputs and stores inputs + outputs as .npz fixtures next to this file.  Nothing of the reference's source is copied
@@ -64,9 +69,25 @@ def load_reference_functions(ref_root, mha_class):
             picked.append(node)
         elif isinstance(node, ast.ClassDef) and node.name == "MultiScaleMaskedTransformerDecoder":
             picked += [n for n in node.body if isinstance(n, ast.FunctionDef) and n.name in WANTED_METHODS]
+    # the decoder class itself, `@configurable` (detectron2's from_config calling convention) not applied to __init__
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == "MultiScaleMaskedTransformerDecoder":
+            for fn in node.body:
+                if isinstance(fn, ast.FunctionDef) and fn.name == "__init__":
+                    fn.decorator_list = []
+            node.decorator_list = []                             # @TRANSFORMER_DECODER_REGISTRY.register(): fvcore registry
+            picked.append(node)
+    import importlib.util
+    import logging
+    spec = importlib.util.spec_from_file_location(
+        "ref_position_encoding2", os.path.join(ref_root, os.path.dirname(DEC), "position_encoding.py"))
+    pe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pe)
     ns = {"torch": torch, "nn": nn, "F": F, "math": math, "Tensor": Tensor, "Optional": Optional,
-          "MultiheadAttention": mha_class, "random": random, "copy": copy}
+          "MultiheadAttention": mha_class, "random": random, "copy": copy, "logging": logging,
+          "PositionEmbeddingSine": pe.PositionEmbeddingSine}
     exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    WANTED_CLASSES.add("MultiScaleMaskedTransformerDecoder")
     missing = (WANTED_FUNCS | WANTED_CLASSES | WANTED_METHODS) - set(ns)
     assert not missing, missing
     return types.SimpleNamespace(**{k: ns[k] for k in WANTED_FUNCS | WANTED_CLASSES | WANTED_METHODS})
@@ -253,6 +274,29 @@ def main():
         arrays["src%d" % i], arrays["pos%d" % i] = srcs[i], poss[i]
     arrays.update({"sd." + k: v.detach().numpy() for k, v in enc.state_dict().items()})
     save("dec_msdeform_encoder", **arrays)
+
+    # ---- the whole transformer decoder, eval mode: 3 layers, 6 queries, 3 feature levels + mask features -------------
+    # (hidden_dim must be 128: gen_sineembed_for_position hard-codes 128 frequencies.)  The parameters are a
+    # deterministic function of their names (tests/golden_params.py), so only inputs and outputs are stored.
+    import sys
+    sys.path.insert(0, os.path.dirname(HERE))
+    from golden_params import deterministic_fill
+    decoder = ref.MultiScaleMaskedTransformerDecoder(
+        128, True, hidden_dim=128, num_queries=6, nheads=8, dim_feedforward=256, dec_layers=3, pre_norm=False,
+        mask_dim=16, enforce_input_project=False, points_num=1, sem_loss_on=False, norm="GN", rel_coord=True).eval()
+    deterministic_fill(decoder, 41)
+    xs = [torch.randn(2, 128, h, w, generator=g) for h, w in ((2, 3), (4, 5), (8, 10))]
+    mfeat = torch.randn(2, 128, 16, 20, generator=g)
+    with torch.no_grad():
+        out = decoder(xs, None, mfeat)
+    arrays = {"x0": xs[0], "x1": xs[1], "x2": xs[2], "mask_features": mfeat, "pred_masks": out["pred_masks"],
+              "reference_points": out["reference_points"], "n_aux": len(out["aux_outputs"]),
+              "param_names": np.asarray(sorted(decoder.state_dict()))}
+    for i, a in enumerate(out["aux_outputs"]):
+        arrays["aux%d_pred_masks" % i] = a["pred_masks"]
+    for i, a in enumerate(out["aux_reference_points"]):
+        arrays["aux%d_reference_points" % i] = a["reference_points"]
+    save("dec_full_decoder", **arrays)
 
     # ---- dice_for (pairwise soft dice of the query masks, used by the query-contrast selection) ---------------------
     m = torch.randn(6, 9, 7, generator=g) * 3

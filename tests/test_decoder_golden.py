@@ -171,3 +171,44 @@ def test_msdeform_encoder_on_the_hip_kernels_matches_the_reference_classes(golde
     with torch.no_grad():
         memory, _, _ = enc(srcs, poss)
     np.testing.assert_allclose(memory.cpu().numpy(), g["memory"], rtol=0, atol=1e-4)
+
+
+def _full_decoder(device):
+    from golden_params import deterministic_fill
+    d = dec.MultiScaleMaskedTransformerDecoder(
+        128, True, hidden_dim=128, num_queries=6, nheads=8, dim_feedforward=256, dec_layers=3, pre_norm=False,
+        mask_dim=16, enforce_input_project=False, points_num=1, sem_loss_on=False, norm="GN", rel_coord=True).eval()
+    return deterministic_fill(d, 41).to(device)
+
+
+def test_whole_decoder_forward_matches_the_reference_class(golden):
+    """MultiScaleMaskedTransformerDecoder.forward in eval mode (dec.py:502-645: the layer loop, level cycling, reference
+    point refinement, controller -> dynamic mask head, attention-mask hand-over) against the reference's own class run
+    on the same name-derived parameters: same parameter names, same predictions, auxiliary outputs and points."""
+    g = golden("dec_full_decoder")
+    d = _full_decoder("cpu")
+    assert sorted(d.state_dict()) == [str(n) for n in g["param_names"]]
+    xs = [_t(g["x%d" % i]) for i in range(3)]
+    with torch.no_grad():
+        out = d(xs, None, _t(g["mask_features"]))
+    scale = max(1.0, float(np.abs(g["pred_masks"]).max()))
+    np.testing.assert_allclose(out["pred_masks"].numpy(), g["pred_masks"], rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(out["reference_points"].numpy(), g["reference_points"], rtol=0, atol=2e-5)
+    assert len(out["aux_outputs"]) == int(g["n_aux"])
+    for i, a in enumerate(out["aux_outputs"]):
+        np.testing.assert_allclose(a["pred_masks"].numpy(), g["aux%d_pred_masks" % i], rtol=0, atol=2e-4 * scale)
+    for i, a in enumerate(out["aux_reference_points"]):
+        np.testing.assert_allclose(a["reference_points"].numpy(), g["aux%d_reference_points" % i], rtol=0, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_whole_decoder_on_the_fused_kernels_matches_the_reference_class(golden):
+    """Same, fp32 on the device: fused dynamic-mask-head kernel + torch attention (fp32 has no MFMA attention path)."""
+    g = golden("dec_full_decoder")
+    d = _full_decoder("cuda")
+    xs = [_t(g["x%d" % i]).cuda() for i in range(3)]
+    with torch.no_grad():
+        out = d(xs, None, _t(g["mask_features"]).cuda())
+    scale = max(1.0, float(np.abs(g["pred_masks"]).max()))
+    np.testing.assert_allclose(out["pred_masks"].cpu().numpy(), g["pred_masks"], rtol=0, atol=5e-4 * scale)
+    np.testing.assert_allclose(out["reference_points"].cpu().numpy(), g["reference_points"], rtol=0, atol=5e-5)
