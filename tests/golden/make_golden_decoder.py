@@ -28,6 +28,13 @@ that never touches its detectron2 names (in_channels == hidden_dim, no forced in
 class is taken from the AST with the `@configurable` decorator of `__init__` (it only adds the from_config calling
 convention) and the class's registry decorator not applied, and constructed with explicit keyword arguments.
 
+From connectomics/model/arch/maskformer.py (instance post-processing): comput_mmi :349-354, dice_for :392-401 and
+mask_post :403-431.  (mask_nms :357-390 uses `np.int`, gone from numpy >= 1.24, and instance_inference imports imageio,
+absent: both are ordinary errors here and stay pinned by literal restatements in the tests.)
+
+From connectomics/model/loss: dice_loss :23-42, sigmoid_ce_loss :50-67, calculate_uncertainty :101-115
+(maskformer_criterion.py) and batch_dice_loss :15-30, batch_sigmoid_ce_loss :38-62 (matcher.py).
+
 This script reads the reference file as text, takes exactly those definitions out of its AST, executes them unmodified
 in a namespace holding torch / nn / F / math (no stand-ins for the missing libraries are written), feeds them seeded
 inputs and stores inputs + outputs as .npz fixtures next to this file.  Nothing of the reference's source is copied
@@ -135,6 +142,31 @@ def load_reference_encoder(ref_root):
           "uniform_": uniform_, "normal_": normal_}
     exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
     return ns["MSDeformAttnTransformerEncoderOnly"]
+
+
+def load_reference_postprocessing(ref_root):
+    path = os.path.join(ref_root, "connectomics/model/arch/maskformer.py")
+    names = {"comput_mmi", "dice_for", "mask_post"}
+    tree = ast.parse(open(path).read(), filename=path)
+    picked = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(picked) == 3
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    return types.SimpleNamespace(**{k: ns[k] for k in names})
+
+
+def load_reference_losses(ref_root):
+    out = {}
+    for rel, names in (("connectomics/model/loss/maskformer_criterion.py", {"dice_loss", "sigmoid_ce_loss", "calculate_uncertainty"}),
+                       ("connectomics/model/loss/matcher.py", {"batch_dice_loss", "batch_sigmoid_ce_loss"})):
+        path = os.path.join(ref_root, rel)
+        tree = ast.parse(open(path).read(), filename=path)
+        picked = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+        assert len(picked) == len(names)
+        ns = {"torch": torch, "F": F, "nn": nn}
+        exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+        out.update({k: ns[k] for k in names})
+    return types.SimpleNamespace(**out)
 
 
 def save(name, **arrays):
@@ -297,6 +329,31 @@ def main():
     for i, a in enumerate(out["aux_reference_points"]):
         arrays["aux%d_reference_points" % i] = a["reference_points"]
     save("dec_full_decoder", **arrays)
+
+    # ---- instance post-processing helpers (arch/maskformer.py) -------------------------------------------------------
+    post = load_reference_postprocessing(args.ref)
+    base = (torch.rand(4, 20, 24, generator=g) > 0.6).float()
+    inst = torch.cat([base, base[:2] * (torch.rand(2, 20, 24, generator=g) > 0.1).float(),        # near-duplicates
+                      (torch.rand(2, 20, 24, generator=g) > 0.7).float()])
+    arrays = {"inst_masks": inst, "dice": post.dice_for(inst),
+              "post_soft": post.mask_post(inst, thres1=0.5, thres2=0.6, bd_flag=False),
+              "post_hard": post.mask_post(inst, thres1=0.5, thres2=0.6, bd_flag=True),
+              "post_bbbc": post.mask_post(inst, thres1=0.15, thres2=0.25)}
+    mm = [(3.0, 5.0, 2.0), (0.0, 4.0, 0.0), (7.0, 7.0, 7.0)]
+    arrays["mmi_in"] = np.asarray(mm, dtype=np.float32)
+    arrays["mmi_out"] = np.asarray([float(post.comput_mmi(torch.tensor(a), torch.tensor(b), torch.tensor(c)))
+                                    for a, b, c in mm], dtype=np.float32)
+    save("arch_mask_post", **arrays)
+
+    # ---- loss / matcher cost definitions ------------------------------------------------------------------------------
+    L = load_reference_losses(args.ref)
+    logits = torch.randn(5, 300, generator=g) * 2
+    tgt = (torch.rand(5, 300, generator=g) > 0.6).float()
+    tgt2 = (torch.rand(3, 300, generator=g) > 0.5).float()
+    save("loss_functions", logits=logits, targets=tgt, targets2=tgt2, num_masks=3.5,
+         dice_loss=L.dice_loss(logits, tgt, 3.5), sigmoid_ce_loss=L.sigmoid_ce_loss(logits, tgt, 3.5),
+         uncertainty=L.calculate_uncertainty(logits[:, None, :]), batch_dice=L.batch_dice_loss(logits, tgt2),
+         batch_ce=L.batch_sigmoid_ce_loss(logits, tgt2))
 
     # ---- dice_for (pairwise soft dice of the query masks, used by the query-contrast selection) ---------------------
     m = torch.randn(6, 9, 7, generator=g) * 3

@@ -212,3 +212,33 @@ def test_whole_decoder_on_the_fused_kernels_matches_the_reference_class(golden):
     scale = max(1.0, float(np.abs(g["pred_masks"]).max()))
     np.testing.assert_allclose(out["pred_masks"].cpu().numpy(), g["pred_masks"], rtol=0, atol=5e-4 * scale)
     np.testing.assert_allclose(out["reference_points"].cpu().numpy(), g["reference_points"], rtol=0, atol=5e-5)
+
+
+def test_instance_postprocessing_helpers_match_the_reference_functions(golden):
+    """arch/maskformer.py of the reference: dice_for (:392-401), mask_post (:403-431; soft / hard merge / BBBC thresholds)
+    and comput_mmi (:349-354)."""
+    from pctrans_amd.arch import maskformer as mfm
+    g = golden("arch_mask_post")
+    inst = _t(g["inst_masks"])
+    np.testing.assert_allclose(mfm.dice_for(inst).numpy(), g["dice"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(mfm.mask_post(inst, thres1=0.5, thres2=0.6, bd_flag=False).numpy(), g["post_soft"],
+                               rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(mfm.mask_post(inst, thres1=0.5, thres2=0.6, bd_flag=True).numpy(), g["post_hard"])
+    np.testing.assert_allclose(mfm.mask_post(inst, thres1=0.15, thres2=0.25).numpy(), g["post_bbbc"], rtol=0, atol=1e-6)
+    for (a, b, c), want in zip(g["mmi_in"], g["mmi_out"]):
+        got = float(mfm.comput_mmi(torch.tensor(float(a)), torch.tensor(float(b)), torch.tensor(float(c))))
+        assert abs(got - float(want)) <= 1e-6 * max(1.0, abs(float(want)))
+
+
+def test_loss_and_matcher_cost_definitions_match_the_reference_functions(golden):
+    """dice_loss / sigmoid_ce_loss / calculate_uncertainty (maskformer_criterion.py:23-115) and batch_dice_loss /
+    batch_sigmoid_ce_loss (matcher.py:15-62) of the reference."""
+    from pctrans_amd.loss import maskformer_criterion as crit
+    from pctrans_amd.loss import matcher
+    g = golden("loss_functions")
+    logits, tgt, tgt2, nm = _t(g["logits"]), _t(g["targets"]), _t(g["targets2"]), float(g["num_masks"])
+    np.testing.assert_allclose(crit.dice_loss(logits, tgt, nm).numpy(), g["dice_loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(crit.sigmoid_ce_loss(logits, tgt, nm).numpy(), g["sigmoid_ce_loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(crit.calculate_uncertainty(logits[:, None, :]).numpy(), g["uncertainty"], rtol=0, atol=0)
+    np.testing.assert_allclose(matcher.batch_dice_loss(logits, tgt2).numpy(), g["batch_dice"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(matcher.batch_sigmoid_ce_loss(logits, tgt2).numpy(), g["batch_ce"], rtol=1e-5, atol=1e-5)
