@@ -66,3 +66,30 @@ def test_product_never_imports_oracle():
                         if re.search(r"(import|from|include|CDLL|-l).*\boracle", line):
                             bad.append((f, line.strip()))
     assert not bad, bad
+
+
+def test_argument_validation_returns_error_codes_without_touching_the_device():
+    """Bad arguments are rejected on the host (no launch, so this runs without a GPU): the C ABI reports errors through
+    return codes, never by printing (the reference printf()s launch failures, cuh:953-957)."""
+    from pctrans_amd import _lib
+    L = _lib.lib()
+    BAD, UNSUP, ALIGN = -1, -4, -3
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p).value                    # 16-byte aligned host pointer: never dereferenced
+    assert p % 16 == 0
+    # linear_k128: negative rows, n not a multiple of 32, misaligned x, row stride below K
+    assert L.pct_linear_k128_f32(p, 128, None, 0, 0, p, p, -1, 128, 0, p, 128, None) == BAD
+    assert L.pct_linear_k128_f32(p, 128, None, 0, 0, p, p, 8, 100, 0, p, 100, None) == UNSUP
+    assert L.pct_linear_k128_f32(p + 4, 128, None, 0, 0, p, p, 8, 128, 0, p, 128, None) == ALIGN
+    assert L.pct_linear_k128_f32(p, 64, None, 0, 0, p, p, 8, 128, 0, p, 128, None) == BAD
+    assert L.pct_linear_k128_f32(p, 128, p, 128, 8, p, p, 64, 128, 0, p, 128, None) == BAD      # add_period < 32
+    assert L.pct_linear_k128_f32(p, 128, None, 0, 0, p, p, 0, 128, 0, p, 128, None) == 0        # empty: OK, no launch
+    # fused output_proj + LayerNorm: missing residual
+    assert L.pct_linear_k128_add_layernorm_f32(p, 128, p, p, None, 128, p, p, 1e-5, 8, p, 128, None) == BAD
+    # GroupNorm + flatten: channels other than 128, groups that do not divide into multiples of 4 channels
+    assert L.pct_groupnorm_flatten_f32(p, p, p, 1, 64, 16, 32, 1e-5, p, p, 2048, 0, None) == UNSUP
+    assert L.pct_groupnorm_flatten_f32(p, p, p, 1, 128, 16, 64, 1e-5, p, p, 2048, 0, None) == UNSUP
+    assert L.pct_groupnorm_flatten_f32(p, p, p, 0, 128, 16, 32, 1e-5, p, p, 2048, 0, None) == 0
+    # add + LayerNorm: unsupported width
+    assert L.pct_add_layernorm_f32(p, None, p, p, 1e-5, 4, 96, p, None) == UNSUP
+    assert b"" != L.pct_error_string(UNSUP)
