@@ -14,9 +14,12 @@ def supported(mask_feats, rel_coord=True):
     return mask_feats.is_cuda and mask_feats.dim() == 4 and mask_feats.shape[1] == 16
 
 
-def dynamic_mask_head_forward(mask_feats, ref_xy, params, stride, rel_coord, target_size, out_dtype=torch.float32):
+def dynamic_mask_head_forward(mask_feats, ref_xy, params, stride, rel_coord, target_size, out_dtype=torch.float32,
+                              feats_f32=None):
     """mask_feats [N, 16, H, W]; ref_xy [N, Q, 2] normalised (x, y); params [N, Q, G] in parse_dynamic_params order.
-    -> (logits upsampled x2 [N, Q, 2H, 2W] in `out_dtype`, attention mask bool [N, Q, th*tw], True = may not attend)."""
+    -> (logits upsampled x2 [N, Q, 2H, 2W] in `out_dtype`, attention mask bool [N, Q, th*tw], True = may not attend).
+    `feats_f32`: optional fp32 contiguous copy of mask_feats made by the caller (the decoder calls this 10 times on the
+    same features)."""
     if not mask_feats.is_cuda:
         raise RuntimeError("Not implemented on the CPU")
     N, C, H, W = mask_feats.shape
@@ -26,7 +29,8 @@ def dynamic_mask_head_forward(mask_feats, ref_xy, params, stride, rel_coord, tar
         raise RuntimeError("params must be [N, Q, %d], got %s" % (G, tuple(params.shape)))
     if out_dtype not in _OUT:
         raise RuntimeError("out_dtype must be float32 or bfloat16")
-    feats = mask_feats.detach().float().contiguous()
+    feats = feats_f32 if feats_f32 is not None else mask_feats.detach().float().contiguous()
+    assert feats.shape == mask_feats.shape and feats.dtype == torch.float32 and feats.is_contiguous()
     prm = params.detach().float().contiguous()
     ref = ref_xy.detach().float().contiguous() if rel_coord else None
     if rel_coord and tuple(ref.shape) != (N, Q, 2):

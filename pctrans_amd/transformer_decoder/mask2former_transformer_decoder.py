@@ -395,13 +395,19 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         reference_points = self.ref_point_head(query_embed).sigmoid()
         ref_points = [reference_points]
 
+        mf_lp = _lp(mask_features)                 # one autocast cast shared by the semantic head and the mask head
         if self.sem_loss_on:
-            sem_logits_pred = self.logits(self.seg_head(mask_features))
-        mask_feat = self.mask_head(mask_features)
+            sem_logits_pred = self.logits(self.seg_head(mf_lp))
+        mask_feat = self.mask_head(mf_lp)
+        # the fused mask-head kernels read fp32 features: convert once, not once per prediction head
+        feats_f32 = None
+        if mask_feat.is_cuda and mask_feat.dtype != torch.float32 and not (
+                torch.is_grad_enabled() and mask_feat.requires_grad):
+            feats_f32 = mask_feat.float().contiguous()
 
         outputs_mask, attn_mask = self.dynamic_mask_with_coords(
             mask_feat, reference_points, self.controller(output), mask_feat_stride=4, rel_coord=self.rel_coord,
-            attn_mask_target_size=size_list[0])
+            attn_mask_target_size=size_list[0], _feats_f32=feats_f32)
         predictions_mask.append(outputs_mask)
         indices = None
         if targets is not None:
@@ -425,20 +431,22 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
 
             out_lp = _lp(output)                       # shared by point_embed / controller (/ next query_scale)
             # iterative reference-point update (gradient flows through the new points only)
-            new_reference_points = (self.point_embed(out_lp) + inverse_sigmoid(reference_points)).sigmoid()
+            # (.float(): a bf16 + fp32 add runs on a slow mixed-dtype kernel, 88 us for 12 800 elements)
+            new_reference_points = (self.point_embed(out_lp).float() + inverse_sigmoid(reference_points)).sigmoid()
             if i != self.num_layers - 1:
                 ref_points.append(new_reference_points)
             reference_points = new_reference_points.detach()
 
             outputs_mask, attn_mask = self.dynamic_mask_with_coords(
                 mask_feat, new_reference_points, self.controller(out_lp), mask_feat_stride=4,
-                rel_coord=self.rel_coord, attn_mask_target_size=size_list[(i + 1) % self.num_feature_levels])
+                rel_coord=self.rel_coord, attn_mask_target_size=size_list[(i + 1) % self.num_feature_levels],
+                _feats_f32=feats_f32)
             if targets is not None:
                 indices = criterion.matcher({"pred_masks": outputs_mask}, targets)
                 indices_list.append(indices)
 
             decoder_output = self.decoder_norm(output).transpose(0, 1)
-            outputs_coord = (self.point_embed(decoder_output)
+            outputs_coord = (self.point_embed(decoder_output).float()
                              + inverse_sigmoid(ref_points[i].transpose(0, 1))).sigmoid()
             predictions_mask.append(outputs_mask)
             outputs_coords.append(outputs_coord)
@@ -464,7 +472,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
 
     # ------------------------------------------------------------------------------------------------------
     def dynamic_mask_with_coords(self, mask_feats, reference_points, mask_head_params, mask_feat_stride, rel_coord,
-                                 attn_mask_target_size):
+                                 attn_mask_target_size, _feats_f32=None):
         """mask_feats [N, C, H, W]; reference_points [Q, N, 2] in [0,1]; mask_head_params [Q, N, num_gen_params].
         -> (mask logits upsampled x2 [N, Q, 2H, 2W], bool attention mask [N, 1, Q, h*w] at `attn_mask_target_size`,
         True = may not attend; broadcast over heads -- the reference returns the same mask repeated per head as
@@ -479,7 +487,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             out_dtype = torch.bfloat16 if mask_feats.dtype == torch.bfloat16 else torch.float32
             mask_logits, amask = dmh.dynamic_mask_head_forward(
                 mask_feats, reference_points.transpose(0, 1), params, mask_feat_stride, rel_coord,
-                attn_mask_target_size, out_dtype=out_dtype)
+                attn_mask_target_size, out_dtype=out_dtype, feats_f32=_feats_f32)
             return mask_logits, amask.unsqueeze(1)
         mask_logits = self.mask_heads_forward_batched(
             mask_feats, reference_points.transpose(0, 1), params, mask_feat_stride, rel_coord)   # [N, Q, H, W]
