@@ -49,8 +49,11 @@ __global__ __launch_bounds__(64) void masked_attention_kernel(const __bf16 *__re
   constexpr int VD = 16;
   const int lane = threadIdx.x, col = lane & 15, g = lane >> 4;
   const int qtiles = (Q + 15) / 16;
-  const int qt = blockIdx.x % qtiles;
-  const int nh = blockIdx.x / qtiles;
+  // XCD-chunked block order: the query tiles of a head, and the heads of an image (whose K rows share 512-B lines),
+  // run on one XCD and hit one L2 instead of eight
+  const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = (int)(lb % (unsigned)qtiles);
+  const int nh = (int)(lb / (unsigned)qtiles);
   const int h = nh % heads, n = nh / heads;
   const int E = heads * HD, EV = heads * VD;
 
