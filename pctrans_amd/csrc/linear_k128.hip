@@ -70,7 +70,7 @@ __global__ __launch_bounds__(LIN_BLOCK, 2) void linear_k128_kernel(
   const int r = lane & 31, h = lane >> 5;
   const int col = blockIdx.y * 128 + wave * 32 + r;          // my W row (B operand) == my output column (C layout)
   // n % 32 == 0: a wave whose 32-column slice lies past n only helps staging the A tiles (wave-uniform)
-  const bool active = blockIdx.y * 128 + wave * 32 < N;
+  const bool active = (int)blockIdx.y * 128 + wave * 32 < N;
 
   float wreg[64];
 #pragma unroll
