@@ -172,6 +172,16 @@ PCT_API int pct_linear_k128_add_layernorm_f32(const float *x, long long ldx, con
                                               const float *beta, float eps, long long rows, float *out,
                                               long long ldo, void *stream);
 
+/* ---- linear sum assignment on the device ------------------------------------------------------------------------
+ * Replaces scipy.optimize.linear_sum_assignment(C.cpu()) of the matcher (connectomics/model/loss/matcher.py:154-165):
+ * for every problem b, cost[b] is [num_query, ld_target] fp32 (row = query / prediction, column = target) of which the
+ * first num_target[b] <= num_query columns are used; row_for_target[b, j] receives the query assigned to target j
+ * (-1 for unused columns) such that the summed cost is minimal.  Same algorithm and fp64 arithmetic as scipy (Crouse's
+ * shortest augmenting paths on the transposed problem).  status[b] = 1 when no finite assignment exists (NaN / +inf
+ * costs).  num_query <= 1024, ld_target <= 512, else PCT_ERR_UNSUPPORTED.  All pointers are device pointers. */
+PCT_API int pct_lsap_f32(const float *cost, int batch, int num_query, int ld_target, const int *num_target,
+                         int *row_for_target, int *status, void *stream);
+
 /* ---- fused masked attention core (MFMA, bf16 operands, fp32 accumulate) ---------------------------------------
  * Replaces q*scale -> bmm(q,k^T) -> masked_fill(-inf) -> softmax -> bmm(p,v) of multi_head_attention_forward
  * (transformer_decoder/attention.py:271-387) for the PCTrans decoder under bf16 autocast.

@@ -27,6 +27,7 @@ int launch_masked_attention(const void *, const void *, const void *, const unsi
                             int, float, int, void *, hipStream_t);
 int launch_groupnorm_flatten(const float *, const float *, const float *, int, int, int, int, float, float *, float *,
                              long long, long long, hipStream_t);
+int launch_lsap(const float *, int, int, int, const int *, int *, int *, hipStream_t);
 int launch_add_layernorm(const float *, const float *, const float *, const float *, float, long long, int, float *,
                          hipStream_t);
 template <typename T>
@@ -276,6 +277,17 @@ int pct_groupnorm_flatten_f32(const float *x, const float *gamma, const float *b
   if ((uintptr_t)x & 15u) return PCT_ERR_ALIGNMENT;
   return pct::launch_groupnorm_flatten(x, gamma, beta, batch, channels, hw, groups, eps, stats, out, out_batch_stride,
                                        out_offset, static_cast<hipStream_t>(stream));
+}
+
+int pct_lsap_f32(const float *cost, int batch, int num_query, int ld_target, const int *num_target, int *row_for_target,
+                 int *status, void *stream)
+{
+  if (batch < 0 || num_query <= 0 || ld_target <= 0) return PCT_ERR_BAD_ARG;
+  if (batch == 0) return PCT_OK;
+  if (!cost || !num_target || !row_for_target || !status) return PCT_ERR_BAD_ARG;
+  const int rc = pct::launch_lsap(cost, batch, num_query, ld_target, num_target, row_for_target, status,
+                                  static_cast<hipStream_t>(stream));
+  return rc == -4 ? PCT_ERR_UNSUPPORTED : rc;
 }
 
 int pct_masked_attention_bf16(const void *q, const void *k, const void *vT, const unsigned char *mask, int batch,

@@ -142,6 +142,26 @@ def groupnorm_flatten_into(x, gn, out, row_offset):
     _lib.check(rc, "groupnorm_flatten")
 
 
+def lsap_supported(cost):
+    return cost.is_cuda and cost.dim() == 3 and cost.shape[1] <= 1024 and cost.shape[2] <= 512
+
+
+def lsap(cost, num_target):
+    """Batched linear sum assignment on the device.  cost [B, Q, Gmax] (row = query, column = target), num_target [B]
+    int32 device tensor with num_target[b] <= Q.  -> (row_for_target [B, Gmax] int32: the query matched to each target,
+    -1 past num_target[b]; status [B] int32: 1 where no finite assignment exists).  No host synchronisation."""
+    c = cost.detach().float().contiguous()
+    B, Q, Gm = c.shape
+    nt = num_target.to(device=c.device, dtype=torch.int32).contiguous()
+    rows = torch.empty((B, Gm), dtype=torch.int32, device=c.device)
+    status = torch.empty((B,), dtype=torch.int32, device=c.device)
+    with torch.cuda.device(c.device):
+        rc = _lib.lib().pct_lsap_f32(c.data_ptr(), B, Q, Gm, nt.data_ptr(), rows.data_ptr(), status.data_ptr(),
+                                     torch.cuda.current_stream(c.device).cuda_stream)
+    _lib.check(rc, "lsap")
+    return rows, status
+
+
 def masked_attention_supported(q, k, v, num_heads, attn_mask, key_padding_mask, dropout_p, training, need_weights):
     """bf16 device tensors, head dims (32|16, 16), boolean mask shared by the heads (or none), forward only."""
     if not (q.is_cuda and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16):

@@ -195,6 +195,8 @@ class SetCriterion(nn.Module):
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(num_masks)
             world = dist.get_world_size()
+        if hasattr(self.matcher, "check"):
+            self.matcher.check()               # device-side assignments: infeasible cost matrices surface here
         num_masks = torch.clamp(num_masks / world, min=1).item()
 
         losses = {}

@@ -36,6 +36,8 @@ class Point_HungarianMatcher(nn.Module):
         self.cost_dice = cost_dice
         assert cost_mask != 0 or cost_dice != 0, "all costs cant be 0"
         self.num_points = num_points
+        self.device_lsap = True            # CUDA inputs: assign on the device; False = scipy on the host (reference)
+        self.pending_status = []
 
     @torch.no_grad()
     def memory_efficient_forward(self, outputs, targets):
@@ -54,9 +56,38 @@ class Point_HungarianMatcher(nn.Module):
                 C = self.cost_mask * batch_sigmoid_ce_loss(out_pts, tgt_pts) \
                     + self.cost_dice * batch_dice_loss(out_pts, tgt_pts)
             costs.append(C.reshape(num_queries, -1))
+        counts = [int(C.shape[1]) for C in costs]
+        if (self.device_lsap and bs > 0 and costs[0].is_cuda and max(counts) <= num_queries
+                and num_queries <= 1024 and max(counts) <= 512):
+            return self._assign_on_device(costs, counts, num_queries)
         # one device -> host transfer per call instead of one per image
         indices = [linear_sum_assignment(C.cpu()) for C in costs]
         return [(torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)) for i, j in indices]
+
+    def _assign_on_device(self, costs, counts, num_queries):
+        """Hungarian matching with the HIP kernel (csrc/lsap.hip): no host synchronisation, the index tensors stay on the
+        device (the reference moves every cost matrix to the host and runs scipy, matcher.py:154-165).  Infeasible
+        problems (NaN / inf costs, where scipy raises) are flagged in `self.pending_status`; `check()` raises for them."""
+        from .. import fused_ops
+        dev = costs[0].device
+        gmax = max(1, max(counts))
+        padded = torch.zeros((len(costs), num_queries, gmax), dtype=torch.float32, device=dev)
+        for b, C in enumerate(costs):
+            if counts[b]:
+                padded[b, :, :counts[b]] = C
+        rows, status = fused_ops.lsap(padded, torch.tensor(counts, dtype=torch.int32).to(dev, non_blocking=True))
+        self.pending_status.append(status)
+        out = []
+        for b, g in enumerate(counts):
+            i, order = torch.sort(rows[b, :g].long())          # scipy lists the pairs by ascending prediction index
+            out.append((i, order))
+        return out
+
+    def check(self):
+        """Raise if any assignment since the last call was infeasible (one host synchronisation)."""
+        pending, self.pending_status = self.pending_status, []
+        if pending and bool(torch.cat(pending).any()):
+            raise ValueError("cost matrix is infeasible (NaN or infinite costs)")
 
     @torch.no_grad()
     def forward(self, outputs, targets):

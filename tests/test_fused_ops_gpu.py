@@ -272,3 +272,61 @@ def test_mfma_attention_kernel_against_the_reference_class_fixture(golden, tag, 
     out = core @ torch.from_numpy(g["out_w"]).cuda().t() + torch.from_numpy(g["out_b"]).cuda()
     want = g["out_bool" if masked else "out_plain"]
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=3e-2 * max(1.0, float(np.abs(want).max())))
+
+
+@pytest.mark.parametrize("Q,counts", [(100, [17, 0, 50, 100, 1]), (300, [120, 299, 3]), (12, [12, 5]), (1000, [400])])
+def test_device_lsap_equals_scipy(Q, counts):
+    """Hungarian matching on the device (csrc/lsap.hip) against scipy.optimize.linear_sum_assignment, the solver the
+    reference's matcher calls: same assignment on generic (tie-free) costs, hence the same total cost."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.RandomState(Q + len(counts))
+    gmax = max(1, max(counts))
+    cost = (rng.standard_normal((len(counts), Q, gmax)) * 3 + rng.random_sample((len(counts), Q, 1))).astype(np.float32)
+    rows, status = fused_ops.lsap(torch.from_numpy(cost).cuda(), torch.tensor(counts, dtype=torch.int32))
+    rows, status = rows.cpu().numpy(), status.cpu().numpy()
+    assert not status.any()
+    for b, g in enumerate(counts):
+        assert (rows[b, g:] == -1).all()
+        if g == 0:
+            continue
+        ri, ci = linear_sum_assignment(cost[b, :, :g].astype(np.float64))
+        want = np.empty(g, dtype=np.int64)
+        want[ci] = ri
+        np.testing.assert_array_equal(rows[b, :g], want)
+
+
+def test_device_lsap_ties_and_infeasible_costs():
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    # heavy ties (integer costs): any optimal assignment is acceptable -> compare the total cost, and validity
+    rng = np.random.RandomState(3)
+    cost = rng.randint(0, 4, size=(2, 40, 25)).astype(np.float32)
+    rows, status = fused_ops.lsap(torch.from_numpy(cost).cuda(), torch.tensor([25, 25], dtype=torch.int32))
+    rows = rows.cpu().numpy()
+    for b in range(2):
+        assert len(set(rows[b].tolist())) == 25 and rows[b].min() >= 0
+        ri, ci = linear_sum_assignment(cost[b].astype(np.float64))
+        assert cost[b][rows[b], np.arange(25)].sum() == cost[b][ri, ci].sum()
+    bad = torch.randn(1, 10, 4).cuda()
+    bad[0, :, 2] = float("nan")
+    _, status = fused_ops.lsap(bad, torch.tensor([4], dtype=torch.int32))
+    assert int(status[0]) == 1
+
+
+def test_matcher_on_device_equals_the_scipy_path():
+    """Point_HungarianMatcher with device assignment vs the reference's host path (scipy) on the same sampled points."""
+    from pctrans_amd.loss.matcher import Point_HungarianMatcher
+    torch.manual_seed(0)
+    pred = torch.randn(3, 50, 32, 32, device="cuda") * 2
+    targets = [{"masks": (torch.rand(g, 64, 64, device="cuda") > 0.5).float()} for g in (7, 0, 20)]
+    m = Point_HungarianMatcher(cost_mask=5.0, cost_dice=5.0, num_points=256)
+    torch.manual_seed(1)
+    on_dev = m({"pred_masks": pred}, targets)
+    m.check()
+    m.device_lsap = False
+    torch.manual_seed(1)                              # same random point coordinates
+    on_host = m({"pred_masks": pred}, targets)
+    for (i, j), (ih, jh) in zip(on_dev, on_host):
+        assert i.is_cuda and i.dtype == torch.int64
+        assert torch.equal(i.cpu(), ih) and torch.equal(j.cpu(), jh)
