@@ -77,6 +77,8 @@ class Point_HungarianMatcher(nn.Module):
                 padded[b, :, :counts[b]] = C
         rows, status = fused_ops.lsap(padded, torch.tensor(counts, dtype=torch.int32).to(dev, non_blocking=True))
         self.pending_status.append(status)
+        if len(self.pending_status) > 256:             # nobody called check(): fold the backlog into one flag tensor
+            self.pending_status = [torch.cat(self.pending_status).max().reshape(1)]
         out = []
         for b, g in enumerate(counts):
             i, order = torch.sort(rows[b, :g].long())          # scipy lists the pairs by ascending prediction index
