@@ -216,14 +216,28 @@ def main():
         if ffn1:
             rows = args.batch * S
             ms1 = sum(ffn1) / len(ffn1)
-            tf = 2.0 * rows * 128 * 1024 / (ms1 * 1e-3) / 1e12
+            split = not os.environ.get("PCT_LIN_KERNEL", "").startswith("f")
+            gemm_tf = 2.0 * rows * 128 * 1024 / (ms1 * 1e-3) / 1e12
+            if split:
+                # linear_k128_split.hip: every fp32 product is evaluated as 6 exact bf16 x bf16 partial products, so the
+                # matrix cores execute 6x the GEMM's flops; utilisation is priced on what they execute, against the
+                # dense bf16 MFMA peak
+                tf, peak = 6.0 * gemm_tf, 2500.0
+                kernel = ("pct::linear_k128_split_kernel<bias+ReLU> (encoder FFN linear1: [%d,128] x [1024,128]^T, fp32 "
+                          "operands as exact 3-way bf16 splits, 6 x v_mfma_f32_32x32x16_bf16 per fp32 MFMA-equivalent)" % rows)
+                note = ("achieved = bf16 MFMA flops executed (6 x the GEMM's 2*rows*128*1024) / launch time; peak = dense "
+                        "bf16 MFMA rate; the same GEMM counted once is gemm_fp32_equiv_tflops (the fp32 MFMA peak is "
+                        "157.3); the step's other large GEMM (linear2, K = 1024) runs on hipBLASLt")
+            else:
+                tf, peak = gemm_tf, 157.3
+                kernel = ("pct::linear_k128_kernel<bias+ReLU> (encoder FFN linear1: [%d,128] x [1024,128]^T, fp32, "
+                          "v_mfma_f32_32x32x2_f32)" % rows)
+                note = ("peak = dense fp32 MFMA rate (256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz); the step's other large "
+                        "GEMM (linear2, K = 1024) runs on hipBLASLt")
             out["roofline_mfma"] = {
-                "kernel": "pct::linear_k128_kernel<bias+ReLU> (encoder FFN linear1: [%d,128] x [1024,128]^T, fp32, "
-                          "v_mfma_f32_32x32x2_f32)" % rows,
-                "bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
-                "mean_launch_ms": ms1, "launches_timed": len(ffn1), "share_of_step": sum(ffn1) / (1e3 * elapsed),
-                "note": "peak = dense fp32 MFMA rate (256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz); the step's other large "
-                        "GEMM (linear2, K = 1024) runs on hipBLASLt",
+                "kernel": kernel, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                "gemm_fp32_equiv_tflops": gemm_tf, "mean_launch_ms": ms1, "launches_timed": len(ffn1),
+                "share_of_step": sum(ffn1) / (1e3 * elapsed), "note": note,
             }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, levels_hw)

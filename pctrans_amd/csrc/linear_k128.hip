@@ -148,11 +148,12 @@ __global__ __launch_bounds__(LIN_BLOCK, 2) void linear_k128_kernel(
     const long long nxt = tile + gridDim.x;
     if (nxt < ntiles) fetch(nxt, g, g2);                          // in flight during the MFMAs
 
-    if (active || EPI == LIN_EPI_RES_LN) {
+    const bool compute = active || EPI == LIN_EPI_RES_LN;
     // two accumulator chains: consecutive MFMAs never wait on each other's result
     lin_f32x16 acc0, acc1;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc0[j] = acc1[j] = 0.f;
+    if (compute) {
     const float *ap = abuf[buf] + a_off;
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
@@ -162,7 +163,12 @@ __global__ __launch_bounds__(LIN_BLOCK, 2) void linear_k128_kernel(
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], wreg[4 * u + 2], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], wreg[4 * u + 3], acc1, 0, 0, 0);
     }
+    }
+    // before this tile's stores are issued: vmcnt counts loads and stores in issue order, a stash placed after the
+    // stores would wait for them to reach memory
+    if (nxt < ntiles) stash(abuf[buf ^ 1], g, g2);
 
+    if (compute) {
     // accumulator layout: acc[j] = C[row = 8*(j/4) + 4*h + j%4][column = r]
     float v[16];
 #pragma unroll
@@ -210,12 +216,17 @@ __global__ __launch_bounds__(LIN_BLOCK, 2) void linear_k128_kernel(
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v[j]), ry, y_voff, (int)((8 * (j / 4) + (j % 4)) * ldy * 4), 0);
     }
 
-    if (nxt < ntiles) stash(abuf[buf ^ 1], g, g2);
     __syncthreads();                  // next image complete; every wave is done reading this one
   }
 }
 
-// n must be a multiple of 32 (LayerNorm variant: exactly 128); x rows 16-byte aligned
+int launch_linear_k128_split(const float *, long long, const float *, long long, long long, const float *, const float *,
+                             long long, int, int, float *, long long, const float *, long long, const float *,
+                             const float *, float, hipStream_t);
+
+// n must be a multiple of 32 (LayerNorm variant: exactly 128); x rows 16-byte aligned.
+// Default: the split-bf16 kernel of linear_k128_split.hip (same results to fp32 accuracy, 6/16 of the MFMA cycles);
+// PCT_LIN_KERNEL=f32 selects the fp32-MFMA kernel of this file (A/B).
 int launch_linear_k128(const float *x, long long ldx, const float *x2, long long ldx2, long long x2_period, const float *w,
                        const float *bias,
                        long long rows, int n, int epi,
@@ -223,6 +234,12 @@ int launch_linear_k128(const float *x, long long ldx, const float *x2, long long
                        const float *beta, float eps, hipStream_t stream)
 {
   if (rows <= 0) return 0;
+  static const bool use_f32 = [] { const char *e = getenv("PCT_LIN_KERNEL"); return e && e[0] == 'f'; }();
+  if (!use_f32) {
+    const int rc = launch_linear_k128_split(x, ldx, x2, ldx2, x2_period, w, bias, rows, n, epi, y, ldy, residual, ldr,
+                                            gamma, beta, eps, stream);
+    if (rc != -100) return rc;                                     // -100: operands not 16-byte aligned for its epilogue
+  }
   const long long ntiles = (rows + 31) / 32;
   static const int wgs = [] { const char *e = getenv("PCT_LIN_WGS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
   const long long cap = 256LL * wgs;                               // persistent: `wgs` workgroups per CU (LDS allows 4)

@@ -1,0 +1,347 @@
+// fp32-accurate skinny GEMM on the bf16 matrix cores of MI355X (gfx950): y = act(x · Wᵀ + b) and the fused
+// y = LayerNorm(residual + x · Wᵀ + b) for the encoder's K = 128 projections -- same contract, operands, epilogues and
+// reference lines as linear_k128.hip (ops/modules/ms_deform_attn.py:64-67,96-110; pixel_decoder/msdeformattn.py:100-131).
+//
+// Why: these GEMMs are bound by the fp32 MFMA rate (157 TFLOP/s peak; linear_k128.hip sustains 123), while the bf16
+// MFMA rate is 16x that.  Every fp32 number is EXACTLY the sum of three bf16 numbers
+//     a = a1 + a2 + a3,   a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)
+// (round-to-nearest leaves a residual below half an ulp of the 8-bit piece, so each piece contributes 9 bits: 27 >= 24;
+// both subtractions are exact in fp32).  A product a·w = sum_ij ai·wj is therefore evaluated from its six leading terms
+//     a1w1 | a1w2 + a2w1 | a2w2 + a1w3 + a3w1          (relative size 1 | 2^-9 | 2^-18)
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16; the dropped terms (a2w3, a3w2,
+// a3w3) are below 2^-26 of the product, i.e. under a quarter of the rounding error fp32 itself commits on it.  The
+// result is as accurate as an fp32 GEMM (measured against fp64 in tests/test_fused_ops_gpu.py) at 6/16 of its MFMA
+// cycles.  Not a reduced-precision path: no input is rounded.
+//
+// Structure (as linear_k128.hip): a wave owns 32 output columns for its whole life, their W rows pre-split into
+// 3 x 32 VGPRs in the B-operand layout; the 4 waves of a workgroup share a 32-row A tile that the workgroup fetches
+// with coalesced dwordx4 buffer loads, splits once (11 VALU per element pair) and keeps as three bf16 planes in a
+// double-buffered LDS image (row stride 272 B: every 16-lane group of a ds_read_b128 covers all 64 banks); per tile a
+// wave issues 48 MFMAs -- the a1w1 chain into one accumulator, the five small terms into a second one, so the small
+// terms are rounded at their own magnitude.  The MFMA computes the TRANSPOSED tile (W pieces as the A operand, x pieces
+// as B): a lane then holds, for ONE row of x, four groups of four consecutive output columns, so the epilogue is
+// dwordx4 all the way (bias/gamma/beta vectors, residual loads, stores -- 4 store instructions per lane and tile
+// instead of 16; with dword stores the kernel was store-issue bound at ~60 cycles per wave store), and a LayerNorm row
+// sum is 15 in-lane adds + one cross-half exchange + one LDS hop across the 4 waves.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+namespace pct {
+
+typedef float spl_f32x16 __attribute__((ext_vector_type(16)));
+typedef float spl_f32x4 __attribute__((ext_vector_type(4)));
+typedef float spl_f32x2 __attribute__((ext_vector_type(2)));
+typedef int spl_i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 spl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 spl_bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SPL_K = 128;
+constexpr int SPL_BLOCK = 256;
+constexpr int SPL_ROWB = 272;                     // bytes per row of a bf16 plane (256 + 16 pad)
+constexpr int SPL_PLANE = 32 * SPL_ROWB;          // one plane of a 32-row tile
+constexpr int SPL_IMAGE = 3 * SPL_PLANE;          // three planes
+constexpr int SPL_OLD = 36;                       // row stride (floats) of a wave's 32 x 32 output scratch
+
+enum { SPL_EPI_BIAS = 0, SPL_EPI_BIAS_RELU = 1, SPL_EPI_RES_LN = 2 };
+
+template <int CTRL>
+__device__ __forceinline__ float spl_dpp(float v)
+{
+  const int i = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, true));
+}
+
+// sum over the 32 lanes of each wave half; result valid in every lane of the half
+__device__ __forceinline__ float spl_half_sum(float v)
+{
+  v += spl_dpp<0xB1>(v);
+  v += spl_dpp<0x4E>(v);
+  v += spl_dpp<0x141>(v);
+  v += spl_dpp<0x140>(v);
+  const int vi = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
+  return (threadIdx.x & 32) ? r2 + r3 : r0 + r1;
+}
+
+// (x, y) -> three packed bf16 pairs (low half = x's piece), x = x1 + x2 + x3 exactly
+__device__ __forceinline__ void spl_split(const float x, const float y, unsigned &p1, unsigned &p2, unsigned &p3)
+{
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(spl_f32x2{x, y}, spl_bf16x2));     // v_cvt_pk_bf16_f32 (RNE)
+  const float rx = x - __uint_as_float(p1 << 16), ry = y - __uint_as_float(p1 & 0xffff0000u);   // exact
+  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(spl_f32x2{rx, ry}, spl_bf16x2));
+  const float sx = rx - __uint_as_float(p2 << 16), sy = ry - __uint_as_float(p2 & 0xffff0000u); // exact
+  p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(spl_f32x2{sx, sy}, spl_bf16x2));
+}
+
+template <int EPI, bool HAS_X2>
+__global__ __launch_bounds__(SPL_BLOCK, 2) void linear_k128_split_kernel(
+    const float *__restrict__ X, const long long ldx, const float *__restrict__ X2, const long long ldx2,
+    const int x2_period, const float *__restrict__ W, const float *__restrict__ bias, const long long M, const int N,
+    float *__restrict__ Y, const long long ldy, const float *__restrict__ R, const long long ldr,
+    const float *__restrict__ gamma, const float *__restrict__ beta, const float eps)
+{
+  __shared__ __attribute__((aligned(16))) unsigned char abuf[2][SPL_IMAGE];
+  __shared__ float red[4][32];                     // LayerNorm: per-wave partial row sums
+  __shared__ __attribute__((aligned(16))) float oscr[4][32 * SPL_OLD];   // per-wave output transpose
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // provably wave-uniform (descriptor selects below)
+  const int r = lane & 31, h = lane >> 5;
+  // 1-D grid of nslots x nslices workgroups (nslots a multiple of 8).  Hardware deals workgroup g to XCD g % 8: the
+  // nslices column slices of one tile slot are given ids that differ by multiples of 8, so they run on the same XCD
+  // at about the same time and the A tile they all read comes out of that XCD's L2 once (with a (tiles, slices) grid
+  // the slices are whole passes apart and x is streamed from HBM once per 128 output columns).
+  const int nslices = (N + 127) / 128;
+  const int nslots = gridDim.x / nslices;
+  const int within = blockIdx.x >> 3;
+  const int slice = within % nslices;
+  const int slot = (within / nslices) * 8 + (blockIdx.x & 7);
+  const int col = slice * 128 + wave * 32 + r;               // my W row (A operand of the transposed product)
+  const bool active = slice * 128 + wave * 32 < N;           // n % 32 == 0: wave-uniform
+
+  // W pieces: step t of the MFMA loop covers k = 16t + 8h + 0..7 on both operands
+  spl_i32x4 w1[8], w2[8], w3[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) w1[t] = w2[t] = w3[t] = spl_i32x4{0, 0, 0, 0};
+  if (active) {
+    const float *wp = W + (long long)col * SPL_K + 8 * h;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const spl_f32x4 lo = *reinterpret_cast<const spl_f32x4 *>(wp + 16 * t);
+      const spl_f32x4 hi = *reinterpret_cast<const spl_f32x4 *>(wp + 16 * t + 4);
+      unsigned a, b, c;
+      spl_split(lo[0], lo[1], a, b, c); w1[t][0] = (int)a; w2[t][0] = (int)b; w3[t][0] = (int)c;
+      spl_split(lo[2], lo[3], a, b, c); w1[t][1] = (int)a; w2[t][1] = (int)b; w3[t][1] = (int)c;
+      spl_split(hi[0], hi[1], a, b, c); w1[t][2] = (int)a; w2[t][2] = (int)b; w3[t][2] = (int)c;
+      spl_split(hi[2], hi[3], a, b, c); w1[t][3] = (int)a; w2[t][3] = (int)b; w3[t][3] = (int)c;
+    }
+  }
+  // accumulator layout of the transposed tile: acc[4q + i] = y[row r][column cbase + 8q + 4h + i]
+  const int cbase = slice * 128 + wave * 32;
+  // LayerNorm: gamma / beta live in LDS (32 fewer VGPRs; 8 ds_read_b128 per tile), visible after the first barrier
+  __shared__ __attribute__((aligned(16))) float gbuf[2][128];
+  if constexpr (EPI == SPL_EPI_RES_LN) {
+    if (tid < 128) gbuf[0][tid] = gamma[tid];
+    else gbuf[1][tid - 128] = beta[tid - 128];
+  }
+  spl_f32x4 bvec[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    bvec[q] = (bias && active) ? *reinterpret_cast<const spl_f32x4 *>(bias + cbase + 8 * q + 4 * h) : spl_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const long long ntiles = (M + 31) / 32;
+  // buffer descriptors re-based on the tile's first row: rows past the end load 0 and their stores are dropped
+  auto tile_rsrc = [&](const float *base, const long long ld, const long long tile) {
+    const long long row0 = tile * 32;
+    const long long left = M - row0;                              // <= 0 past the end: an empty descriptor
+    const unsigned bytes = (unsigned)((left < 32 ? (left < 0 ? 0 : left) : 32) * ld * 4);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + row0 * ld), 0, (int)bytes, 0x00020000);
+  };
+  // A tile = 32 rows x 128 floats = 1024 float4; thread tid moves float4 number tid + 256*q (row 8q + tid/32)
+  const int g_voff = (int)((tid >> 5) * ldx * 4) + 16 * (tid & 31);
+  const int g_step = (int)(8 * ldx * 4);
+  const int s_off = (tid >> 5) * SPL_ROWB + 8 * (tid & 31);         // 4 bf16 = 8 B per float4 and plane
+  const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(HAS_X2 ? X2 : X), 0,
+                                                     (int)((long long)x2_period * ldx2 * 4), 0x00020000);
+  auto fetch = [&](const long long tile, spl_i32x4 (&g)[4]) {
+    const auto rs = tile_rsrc(X, ldx, tile);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, g_voff, q * g_step, 0);
+  };
+  // the x2 rows (the positional term, shared by the batch: L2 hits) are fetched one tile ahead only: one register set
+  auto fetch2 = [&](const long long tile, spl_i32x4 (&g2)[4]) {
+    if constexpr (HAS_X2) {
+      const int base = (int)((tile * 32) % x2_period);              // uniform
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int row = base + (tid >> 5) + 8 * q;
+        row = row >= x2_period ? row - x2_period : row;
+        g2[q] = __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)(row * ldx2 * 4) + 16 * (tid & 31), 0, 0);
+      }
+    }
+  };
+  auto stash = [&](unsigned char *dst, const spl_i32x4 (&g)[4], const spl_i32x4 (&g2)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      spl_f32x4 v = __builtin_bit_cast(spl_f32x4, g[q]);
+      if constexpr (HAS_X2) v += __builtin_bit_cast(spl_f32x4, g2[q]);
+      unsigned a0, b0, c0, a1, b1, c1;
+      spl_split(v[0], v[1], a0, b0, c0);
+      spl_split(v[2], v[3], a1, b1, c1);
+      unsigned char *p = dst + s_off + q * 8 * SPL_ROWB;
+      *reinterpret_cast<uint2 *>(p) = make_uint2(a0, a1);
+      *reinterpret_cast<uint2 *>(p + SPL_PLANE) = make_uint2(b0, b1);
+      *reinterpret_cast<uint2 *>(p + 2 * SPL_PLANE) = make_uint2(c0, c1);
+    }
+  };
+
+  // stores: lane -> row lane/8 (+8i), 16 B at column 4*(lane%8): a wave instruction writes 8 full 128-B lines
+  const int y_voff = (int)(((lane >> 3) * ldy + cbase + 4 * (lane & 7)) * 4);
+  const int y_step = (int)(8 * ldy * 4);
+  const int r_voff = (int)((r * ldr + cbase + 4 * h) * 4);
+  const int a_off = r * SPL_ROWB + 16 * h;
+
+  // Two tiles of x are in flight per workgroup (register sets ga / gb): under load a fetch takes longer than one
+  // tile's MFMAs, and with a single tile of prefetch the iteration time is the memory latency (measured 3.2 us per
+  // tile whatever n).  Issue order inside an iteration is what the in-order vmcnt makes cheap: [residual rows of this
+  // tile, x of tile+2] -> MFMAs -> split + stash of tile+1 (the oldest loads) -> epilogue (waits only for the residual,
+  // which is older than the far fetch) -> stores.
+  spl_i32x4 ga[4], gb[4], g2[4] = {};
+  auto body = [&](const long long tile, const int buf, spl_i32x4 (&gn)[4], spl_i32x4 (&gf)[4]) {
+    const long long far = tile + 2 * (long long)nslots;
+    spl_i32x4 res[4];
+    if constexpr (EPI == SPL_EPI_RES_LN) {
+      const auto rr = tile_rsrc(R, ldr, tile);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) res[q] = __builtin_amdgcn_raw_buffer_load_b128(rr, r_voff, 32 * q, 0);
+    }
+    fetch2(tile + nslots, g2);
+    fetch(far, gf);                                               // past the end: empty descriptor, returns zeros
+    __builtin_amdgcn_sched_barrier(0);                            // keep the fetches ahead of the MFMAs
+
+    spl_f32x16 acc_hi, acc_lo;                                    // a1w1 | the five small terms
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc_hi[j] = acc_lo[j] = 0.f;
+    {                                                             // (a wave past n multiplies zeros: no branch, so
+      const unsigned char *ap = abuf[buf] + a_off;                //  the compiler's vmcnt bookkeeping stays exact)
+      // the three pieces of step t+1 are read while step t's MFMAs run (the wave issues in order: reads placed
+      // after the MFMAs would leave the matrix pipe idle for an LDS round trip per step)
+      spl_bf16x8 n1 = *reinterpret_cast<const spl_bf16x8 *>(ap);
+      spl_bf16x8 n2 = *reinterpret_cast<const spl_bf16x8 *>(ap + SPL_PLANE);
+      spl_bf16x8 n3 = *reinterpret_cast<const spl_bf16x8 *>(ap + 2 * SPL_PLANE);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const spl_bf16x8 a1 = n1, a2 = n2, a3 = n3;
+        if (t < 7) {
+          n1 = *reinterpret_cast<const spl_bf16x8 *>(ap + 32 * (t + 1));
+          n2 = *reinterpret_cast<const spl_bf16x8 *>(ap + 32 * (t + 1) + SPL_PLANE);
+          n3 = *reinterpret_cast<const spl_bf16x8 *>(ap + 32 * (t + 1) + 2 * SPL_PLANE);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const spl_bf16x8 b1 = __builtin_bit_cast(spl_bf16x8, w1[t]);
+        const spl_bf16x8 b2 = __builtin_bit_cast(spl_bf16x8, w2[t]);
+        const spl_bf16x8 b3 = __builtin_bit_cast(spl_bf16x8, w3[t]);
+        acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a3, acc_lo, 0, 0, 0);
+        acc_hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc_hi, 0, 0, 0);
+        acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, a1, acc_lo, 0, 0, 0);
+        acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a2, acc_lo, 0, 0, 0);
+        acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a2, acc_lo, 0, 0, 0);
+        acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a1, acc_lo, 0, 0, 0);
+      }
+    }
+    stash(abuf[buf ^ 1], gn, g2);
+
+    {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = (acc_hi[j] + acc_lo[j]) + bvec[j / 4][j % 4];
+
+      if constexpr (EPI == SPL_EPI_RES_LN) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] += __int_as_float(res[j / 4][j % 4]);
+        // two-pass LayerNorm over the row's 128 columns: my 16, the other half of the wave (lane ^ 32), the 4 waves
+        auto row_sum = [&](const float (&x)[16]) {
+          float t = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7])) +
+                    (((x[8] + x[9]) + (x[10] + x[11])) + ((x[12] + x[13]) + (x[14] + x[15])));
+          t += __shfl_xor(t, 32);
+          return t;
+        };
+        float part = row_sum(v);
+        if (h == 0) red[wave][r] = part;
+        __syncthreads();
+        const float mean = ((red[0][r] + red[1][r]) + (red[2][r] + red[3][r])) * (1.f / 128.f);
+        float sq[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          v[j] -= mean;
+          sq[j] = v[j] * v[j];
+        }
+        part = row_sum(sq);
+        __syncthreads();                                          // red free again
+        if (h == 0) red[wave][r] = part;
+        __syncthreads();
+        const float rstd = rsqrtf(((red[0][r] + red[1][r]) + (red[2][r] + red[3][r])) * (1.f / 128.f) + eps);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const spl_f32x4 gq = *reinterpret_cast<const spl_f32x4 *>(&gbuf[0][wave * 32 + 8 * q + 4 * h]);
+          const spl_f32x4 bq = *reinterpret_cast<const spl_f32x4 *>(&gbuf[1][wave * 32 + 8 * q + 4 * h]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[4 * q + i] = v[4 * q + i] * rstd * gq[i] + bq[i];
+        }
+      } else if constexpr (EPI == SPL_EPI_BIAS_RELU) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      const auto ry = tile_rsrc(Y, ldy, active ? tile : ntiles);   // a wave past n stores nothing
+      // through the wave's own LDS scratch (in-order DS ops of one wave: no barrier): the accumulator layout has a
+      // row's 32 columns in 8 pieces over two lanes; stored directly, every instruction touched 32 lines for 32 B
+      // each (measured slower than dword stores); re-read so that 8 lanes hold one row's 128 contiguous bytes
+      float *sw = oscr[wave];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<spl_f32x4 *>(sw + r * SPL_OLD + 8 * q + 4 * h) = spl_f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const spl_f32x4 o = *reinterpret_cast<const spl_f32x4 *>(sw + ((lane >> 3) + 8 * i) * SPL_OLD + 4 * (lane & 7));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(spl_i32x4, o), ry, y_voff, i * y_step, 0);
+      }
+    }
+    __syncthreads();                  // next image complete; every wave is done reading this one
+  };
+
+  long long tile = slot;
+  fetch(tile, ga);
+  fetch2(tile, g2);
+  stash(abuf[0], ga, g2);
+  fetch(tile + nslots, ga);
+  // the per-column constants are complete before the loop (otherwise their pending loads cost a vmcnt(0) per tile)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    asm volatile("" : "+v"(bvec[q]));
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += 2 * (long long)nslots) {
+    body(tile, 0, ga, gb);
+    if (tile + nslots < ntiles) body(tile + nslots, 1, gb, ga);
+  }
+}
+
+// n must be a multiple of 32 (LayerNorm variant: exactly 128); x rows 16-byte aligned.  Returns -100 when the
+// operands do not allow the dwordx4 epilogue (caller uses the fp32-MFMA kernel).
+int launch_linear_k128_split(const float *x, long long ldx, const float *x2, long long ldx2, long long x2_period,
+                             const float *w, const float *bias, long long rows, int n, int epi, float *y, long long ldy,
+                             const float *residual, long long ldr, const float *gamma, const float *beta, float eps,
+                             hipStream_t stream)
+{
+  if (rows <= 0) return 0;
+  if ((((uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)gamma | (uintptr_t)beta) & 15u) || (ldy & 3) ||
+      (ldr & 3))
+    return -100;
+  const long long ntiles = (rows + 31) / 32;
+  static const int wgs = [] { const char *e = getenv("PCT_LIN_WGS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 2 ? 2 : v); }();
+  const int nslices = (n + 127) / 128;
+  // persistent: 2 workgroups per CU (VGPRs) when one slice covers n, else tile slots x slices (see the kernel)
+  long long nslots = 256LL * wgs / (nslices < 8 ? nslices : 8) / 8 * 8;      // all resident at once
+  if (nslots > (ntiles + 7) / 8 * 8) nslots = (ntiles + 7) / 8 * 8;
+  if (nslots < 8) nslots = 8;
+  const dim3 grid((unsigned)(nslots * nslices)), block(SPL_BLOCK);
+#define PCT_SPL(EPI_, X2_)                                                                                           \
+  hipLaunchKernelGGL((linear_k128_split_kernel<EPI_, X2_>), grid, block, 0, stream, x, ldx, x2, ldx2, (int)x2_period, w, \
+                     bias, rows, n, y, ldy, residual, ldr, gamma, beta, eps)
+  if (x2) {
+    if (epi == SPL_EPI_BIAS) PCT_SPL(SPL_EPI_BIAS, true);
+    else if (epi == SPL_EPI_BIAS_RELU) PCT_SPL(SPL_EPI_BIAS_RELU, true);
+    else return -100;                                              // not instantiated (nothing uses it; it would spill)
+  } else {
+    if (epi == SPL_EPI_BIAS) PCT_SPL(SPL_EPI_BIAS, false);
+    else if (epi == SPL_EPI_BIAS_RELU) PCT_SPL(SPL_EPI_BIAS_RELU, false);
+    else PCT_SPL(SPL_EPI_RES_LN, false);
+  }
+#undef PCT_SPL
+  return (int)hipGetLastError();
+}
+
+}  // namespace pct

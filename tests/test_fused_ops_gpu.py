@@ -148,6 +148,50 @@ def test_linear_k128_matches_fp64_matmul(rows, n, relu, bias):
     assert (got.double() - want).abs().max() <= 2.0 * (lib.double() - want).abs().max() + 1e-6
 
 
+def test_linear_k128_split_products_keep_fp32_accuracy_over_the_exponent_range():
+    """The default kernel evaluates x·Wᵀ on the bf16 matrix cores from the exact three-way bf16 split of every fp32
+    operand (six leading partial products, fp32 accumulation).  Per-row / per-column scales from 1e-12 to 1e12 and
+    heavy cancellation: the error relative to sum_k |x_k w_k| must stay at the level of an fp32 dot product
+    (128 terms: a few 2^-24), far below what any single bf16 rounding (2^-9) would leave."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rows, n = 8192, 256
+    x = torch.randn(rows, 128, device="cuda", generator=g)
+    w = torch.randn(n, 128, device="cuda", generator=g)
+    x = x * torch.logspace(-12, 12, rows, device="cuda")[torch.randperm(rows, device="cuda", generator=g)][:, None]
+    w = w * torch.logspace(-12, 12, n, device="cuda")[:, None]
+    x[:, 64:] = -x[:, :64] * (1 + 1e-3 * torch.randn(rows, 64, device="cuda", generator=g))     # cancellation
+    w[:, 64:] = w[:, :64]
+    got = fused_ops.linear_k128(x, w)
+    want = x.double() @ w.double().t()
+    scale = x.double().abs() @ w.double().abs().t()
+    err = ((got.double() - want).abs() / scale).max().item()
+    lib = ((torch.nn.functional.linear(x, w).double() - want).abs() / scale).max().item()
+    assert err < 4e-7, err                                  # fp32: unit roundoff 6e-8, 128-term accumulation
+    assert err <= 2.0 * lib + 1e-8, (err, lib)
+
+
+def test_linear_k128_fp32_mfma_variant_still_matches(tmp_path):
+    """PCT_LIN_KERNEL=f32 selects the fp32-MFMA kernel (kept for A/B); the switch is read once per process."""
+    import subprocess, sys, os
+    code = (
+        "import torch, sys; sys.path.insert(0, %r)\n"
+        "from pctrans_amd import fused_ops\n"
+        "torch.manual_seed(0)\n"
+        "x = torch.randn(5000, 128, device='cuda'); lin = torch.nn.Linear(128, 384).cuda()\n"
+        "res = torch.randn(5000, 128, device='cuda'); norm = torch.nn.LayerNorm(128).cuda(); l2 = torch.nn.Linear(128, 128).cuda()\n"
+        "with torch.no_grad():\n"
+        "    got = fused_ops.linear_k128(x, lin.weight, lin.bias, relu=True)\n"
+        "    want = (x.double() @ lin.weight.double().t() + lin.bias.double()).relu()\n"
+        "    assert (got.double() - want).abs().max().item() < 2e-5\n"
+        "    got = fused_ops.linear_add_layer_norm(x, l2, res, norm)\n"
+        "    want = torch.nn.functional.layer_norm(res.double() + x.double() @ l2.weight.double().t() + l2.bias.double(), (128,), norm.weight.double(), norm.bias.double(), norm.eps)\n"
+        "    assert (got.double() - want).abs().max().item() < 2e-5\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, PCT_LIN_KERNEL="f32")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("S,shared", [(5000, False), (5376, True), (7481, True), (33, True)])
 def test_linear_k128_adds_the_positional_operand_on_the_fly(S, shared):
     """x_add = the encoder's positional term: per image, or one [1, S, 128] tensor shared by the batch (the kernel
