@@ -172,6 +172,19 @@ PCT_API int pct_linear_k128_add_layernorm_f32(const float *x, long long ldx, con
                                               const float *beta, float eps, long long rows, float *out,
                                               long long ldo, void *stream);
 
+/* ---- Linear (any K) + residual + LayerNorm(128), fp32 -------------------------------------------------------------
+ * pct_linear_add_layernorm_f32:  out[rows, 128] = LayerNorm(residual + x[rows, k] . w[128, k]^T + bias) * gamma + beta.
+ *   Replaces the encoder FFN's `src2 = linear2(...)`, `src = src + dropout3(src2)`, `src = norm2(src)`
+ *   (pixel_decoder/msdeformattn.py:122-131; dim_feedforward = 1024), eval mode (dropout = identity).
+ *   fp32-accurate product on the bf16 matrix cores from exact three-way bf16 splits of both operands (see
+ *   pctrans_amd/csrc/linear_ln_split.hip).  k % 32 == 0 (else PCT_ERR_UNSUPPORTED); x, w, residual, out, bias, gamma,
+ *   beta 16-byte aligned, ldx / ldr / ldo % 4 == 0; w_split_ws = device workspace of 3 * 128 * k * 2 bytes (16-byte
+ *   aligned) that the call overwrites with the split weights; out may alias residual. */
+PCT_API int pct_linear_add_layernorm_f32(const float *x, long long ldx, int k, const float *w, void *w_split_ws,
+                                         const float *bias, const float *residual, long long ldr, const float *gamma,
+                                         const float *beta, float eps, long long rows, float *out, long long ldo,
+                                         void *stream);
+
 /* ---- linear sum assignment on the device ------------------------------------------------------------------------
  * Replaces scipy.optimize.linear_sum_assignment(C.cpu()) of the matcher (connectomics/model/loss/matcher.py:154-165):
  * for every problem b, cost[b] is [num_query, ld_target] fp32 (row = query / prediction, column = target) of which the

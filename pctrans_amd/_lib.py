@@ -27,6 +27,8 @@ SYMBOLS = {
                              ctypes.c_longlong, _vp], _i),
     "pct_linear_k128_add_layernorm_f32": ([_vp, ctypes.c_longlong, _vp, _vp, _vp, ctypes.c_longlong, _vp, _vp,
                                            ctypes.c_float, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp], _i),
+    "pct_linear_add_layernorm_f32": ([_vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp, _vp,
+                                      ctypes.c_float, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp], _i),
     "pct_groupnorm_flatten_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, ctypes.c_longlong,
                                    ctypes.c_longlong, _vp], _i),
     "pct_lsap_f32": ([_vp, _i, _i, _i, _vp, _vp, _vp, _vp], _i),

@@ -17,6 +17,9 @@ int launch_linear_k128(const float *x, long long ldx, const float *x2, long long
                        long long rows, int n, int epi,
                        float *y, long long ldy, const float *residual, long long ldr, const float *gamma,
                        const float *beta, float eps, hipStream_t stream);
+int launch_linear_ln_split(const float *x, long long ldx, const float *w, unsigned short *w_pieces, int K, const float *bias,
+                           const float *residual, long long ldr, const float *gamma, const float *beta, float eps,
+                           long long rows, float *out, long long ldo, hipStream_t stream);
 template <typename A>
 int launch_msda_backward(const void *, const int64_t *, const int64_t *, const void *, const void *, const void *,
                          int, int, int, int, int, int, int, void *, void *, void *, hipStream_t);
@@ -264,6 +267,22 @@ int pct_linear_k128_add_layernorm_f32(const float *x, long long ldx, const float
   if ((((uintptr_t)x | (uintptr_t)w) & 15u) || (ldx & 3)) return PCT_ERR_ALIGNMENT;
   return pct::launch_linear_k128(x, ldx, nullptr, 0, 0, w, bias, rows, 128, 2, out, ldo, residual, ldr, gamma, beta, eps,
                                  static_cast<hipStream_t>(stream));
+}
+
+int pct_linear_add_layernorm_f32(const float *x, long long ldx, int k, const float *w, void *w_split_ws, const float *bias,
+                                 const float *residual, long long ldr, const float *gamma, const float *beta, float eps,
+                                 long long rows, float *out, long long ldo, void *stream)
+{
+  if (rows < 0 || k <= 0 || ldx < k || ldr < 128 || ldo < 128) return PCT_ERR_BAD_ARG;
+  if (rows == 0) return PCT_OK;
+  if (!x || !w || !w_split_ws || !residual || !gamma || !beta || !out) return PCT_ERR_BAD_ARG;
+  if (k % 32) return PCT_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)w_split_ws | (uintptr_t)residual | (uintptr_t)out | (uintptr_t)bias |
+        (uintptr_t)gamma | (uintptr_t)beta) & 15u) || (ldx & 3) || (ldr & 3) || (ldo & 3))
+    return PCT_ERR_ALIGNMENT;
+  const int rc = pct::launch_linear_ln_split(x, ldx, w, static_cast<unsigned short *>(w_split_ws), k, bias, residual, ldr, gamma,
+                                             beta, eps, rows, out, ldo, static_cast<hipStream_t>(stream));
+  return rc == -4 ? PCT_ERR_UNSUPPORTED : rc;
 }
 
 int pct_groupnorm_flatten_f32(const float *x, const float *gamma, const float *beta, int batch, int channels, int hw,

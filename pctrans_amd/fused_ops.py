@@ -122,6 +122,48 @@ def linear_add_layer_norm(x, linear, residual, norm):
     return out.view(residual.shape)
 
 
+_SPLIT_WS = {}                                   # (device, K) -> workspace the kernel refills with the split weights
+
+
+def linear_layer_norm_supported(x, linear, residual, norm):
+    """fp32 device tensors, Linear(K -> 128) with K % 32 == 0 followed by residual add and LayerNorm(128), forward only."""
+    w = linear.weight
+    return (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and w.device == x.device
+            and w.is_contiguous() and linear.out_features == 128 and linear.in_features % 32 == 0
+            and x.shape[-1] == linear.in_features and x.numel() > 0 and x.stride(-1) == 1
+            and residual.dtype == torch.float32 and residual.device == x.device and residual.shape[-1] == 128
+            and residual.shape[:-1] == x.shape[:-1] and residual.stride(-1) == 1
+            and isinstance(norm, torch.nn.LayerNorm) and tuple(norm.normalized_shape) == (128,)
+            and norm.weight is not None and norm.bias is not None and not torch.is_autocast_enabled()
+            and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or residual.requires_grad)))
+
+
+def linear_layer_norm(x, linear, residual, norm):
+    """norm(residual + linear(x)) for Linear(K -> 128) + LayerNorm(128): the encoder FFN's linear2 / dropout3 / norm2
+    (pixel_decoder/msdeformattn.py:122-131) as one kernel; the [rows, 128] product never goes to memory."""
+    if not linear_layer_norm_supported(x, linear, residual, norm):
+        return add_layer_norm(residual, linear(x), norm)
+    x2, r2 = _rows_2d(x), _rows_2d(residual)
+    rows, k = x2.shape
+    aligned = all(t.data_ptr() % 16 == 0 for t in (x2, r2, linear.weight, norm.weight, norm.bias)) and \
+        (linear.bias is None or linear.bias.data_ptr() % 16 == 0) and x2.stride(0) % 4 == 0 and r2.stride(0) % 4 == 0
+    if not aligned:
+        return add_layer_norm(residual, linear(x), norm)
+    key = (x.device, k)
+    ws = _SPLIT_WS.get(key)
+    if ws is None:
+        ws = _SPLIT_WS[key] = torch.empty((3, 128, k), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((rows, 128), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timing.timed("linear_ln k=%d" % k, x2):
+        rc = _lib.lib().pct_linear_add_layernorm_f32(
+            x2.data_ptr(), x2.stride(0), k, linear.weight.data_ptr(), ws.data_ptr(),
+            linear.bias.data_ptr() if linear.bias is not None else None, r2.data_ptr(), r2.stride(0),
+            norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps), rows, out.data_ptr(), 128,
+            torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "linear_layer_norm")
+    return out.view(residual.shape)
+
+
 def groupnorm_flatten_supported(x, gn):
     """fp32 NCHW device tensor, 128 channels, groups of a multiple of 4 channels, affine, forward only."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 128 and x.is_contiguous()

@@ -69,8 +69,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
 
     def forward_ffn(self, src):
         if self._eval_fused(src):
-            src2 = self.linear2(fused_ops.linear(src, self.linear1, relu=True))
-            return fused_ops.add_layer_norm(src, src2, self.norm2)
+            return fused_ops.linear_layer_norm(fused_ops.linear(src, self.linear1, relu=True), self.linear2, src, self.norm2)
         src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
         return self.norm2(src + self.dropout3(src2))
 

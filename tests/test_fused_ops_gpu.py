@@ -233,6 +233,57 @@ def test_linear_add_layer_norm_equals_unfused(rows):
     torch.testing.assert_close(got.double(), want, rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("rows,k", [(21760, 1024), (4099, 1024), (130, 256), (128, 32), (7, 2048)])
+def test_linear_layer_norm_any_k_matches_fp64(rows, k):
+    """Encoder FFN tail: norm2(src + linear2(h)) as one tiled GEMM on split-bf16 operands (linear_ln_split.hip),
+    ragged last tile, several K; against fp64 at the fp32 noise level of a K-term dot product + LayerNorm."""
+    torch.manual_seed(rows + k)
+    lin = torch.nn.Linear(k, 128).cuda()
+    norm = torch.nn.LayerNorm(128).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+        x = torch.randn(2, rows, k, device="cuda").relu_()
+        res = torch.randn(2, rows, 128, device="cuda") * 3 + 1.5
+        assert fused_ops.linear_layer_norm_supported(x, lin, res, norm)
+        got = fused_ops.linear_layer_norm(x, lin, res, norm)
+        want = torch.nn.functional.layer_norm(res.double() + x.double() @ lin.weight.double().t() + lin.bias.double(),
+                                              (128,), norm.weight.double(), norm.bias.double(), norm.eps)
+        lib = fused_ops.add_layer_norm(res, lin(x), norm)
+    assert got.shape == res.shape
+    torch.testing.assert_close(got.double(), want, rtol=0, atol=2e-5)
+    assert (got.double() - want).abs().max() <= 2.0 * (lib.double() - want).abs().max() + 1e-6
+
+
+def test_linear_layer_norm_pre_norm_sum_keeps_fp32_accuracy_over_the_exponent_range():
+    """The product inside the fused kernel, isolated: gamma = 1, beta = 0 and a residual that dominates the row, so
+    that LayerNorm is (nearly) affine in the product; operands scaled from 1e-6 to 1e6 per column of x."""
+    torch.manual_seed(3)
+    k, rows = 1024, 4096
+    lin = torch.nn.Linear(k, 128, bias=False).cuda()
+    norm = torch.nn.LayerNorm(128).cuda()
+    with torch.no_grad():
+        x = torch.randn(rows, k, device="cuda") * torch.logspace(-6, 6, k, device="cuda")[torch.randperm(k, device="cuda")]
+        lin.weight.mul_(1.0 / torch.logspace(-6, 6, k, device="cuda")[torch.randperm(k, device="cuda")])
+        res = torch.zeros(rows, 128, device="cuda")
+        got = fused_ops.linear_layer_norm(x, lin, res, norm)
+        prod = x.double() @ lin.weight.double().t()
+        want = torch.nn.functional.layer_norm(prod, (128,), None, None, norm.eps)
+        lib = torch.nn.functional.layer_norm(lin(x), (128,), None, None, norm.eps)
+    err, lib_err = (got.double() - want).abs().max().item(), (lib.double() - want).abs().max().item()
+    assert err <= 2.0 * lib_err + 1e-6, (err, lib_err)
+
+
+def test_linear_layer_norm_falls_back_when_unsupported():
+    lin = torch.nn.Linear(100, 128).cuda()              # K % 32 != 0
+    norm = torch.nn.LayerNorm(128).cuda()
+    x, res = torch.randn(50, 100, device="cuda"), torch.randn(50, 128, device="cuda")
+    with torch.no_grad():
+        assert not fused_ops.linear_layer_norm_supported(x, lin, res, norm)
+        got = fused_ops.linear_layer_norm(x, lin, res, norm)
+        torch.testing.assert_close(got, norm(res + lin(x)), rtol=1e-5, atol=1e-5)
+
+
 def test_cached_linear_equals_autocast_linear_and_follows_weight_updates():
     from pctrans_amd.layers import CachedLinear
     torch.manual_seed(3)

@@ -46,3 +46,10 @@ with torch.no_grad():
         t_sep = timed(lambda: fused_ops.linear_k128(x + pos, lin.weight, lin.bias))
         t_fused = timed(lambda: fused_ops.linear_k128(x, lin.weight, lin.bias, x_add=pos))
         print("n=%4d (x + pos): add kernel + linear_k128 %.3f ms   x_add operand %.3f ms" % (n, t_sep, t_fused))
+    lin2 = torch.nn.Linear(1024, 128).cuda()
+    hdn = torch.randn(rows, 1024, device="cuda").relu_()
+    t_lib = timed(lambda: fused_ops.add_layer_norm(res, lin2(hdn), norm))
+    t_own = timed(lambda: fused_ops.linear_layer_norm(hdn, lin2, res, norm))
+    fl = 2.0 * rows * 1024 * 128
+    print("linear2 (K=1024) + residual + LayerNorm: library GEMM + add_layernorm %.3f ms   fused split-bf16 %.3f ms (%.0f TF/s fp32-equivalent)" % (
+        t_lib, t_own, fl / t_own / 1e9))
