@@ -255,18 +255,17 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
       }
     }
     stamp(3);
-    __syncthreads();                                               // (2) windows staged
-    stamp(4);
-
-    // ---- gather, one slot after the other; the next slot's points are in flight meanwhile ----------------------
-    const ST *vlane = vimg + c * VEC;                               // + lane's channel slice (global path)
-    const unsigned char *pool_lane = pool + c * 16;
+    // ---- gather, one slot after the other.  A slot's points (and, FUSED, its reference points) are only ISSUED here;
+    // the front-end arithmetic that consumes them runs a whole slot later (`finish_points`), so the wave never sits
+    // on a fresh load: the first slot's loads are in flight across barrier (2) together with the LDS-DMA pieces, slot
+    // s+1's during slot s's gather.  (With the arithmetic right behind the loads -- the first version -- every slot
+    // began with a full memory round trip: `s_waitcnt vmcnt(0)` directly after the ten loads.) -------------------------
     float nx[L][PPL], ny[L][PPL], nw[L][PPL];
-    auto load_points = [&](long long rec, int qi) {
+    f32x2 nr[FUSED ? L : 1];
+    auto issue_points = [&](long long rec, int qi) {
       const long long r = rec < 0 ? 0 : rec;
       const float *lrec = loc + r * (L * P * 2) + c * 2;
       const float *wrec = attn + r * (L * P) + c;
-      const float *rrow = FUSED ? ref + b * ref_batch_stride + (long long)qi * (L * 2) : nullptr;
 #pragma unroll
       for (int l = 0; l < L; ++l)
 #pragma unroll
@@ -275,12 +274,29 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
           nx[l][k] = xy[0];
           ny[l][k] = xy[1];
           nw[l][k] = wrec[l * P + k * QL];
-          if constexpr (FUSED) {
-            const f32x2 rr = *reinterpret_cast<const f32x2 *>(rrow + 2 * l);
-            nx[l][k] = fmaf(xy[0], invW[l], rr[0]);
-            ny[l][k] = fmaf(xy[1], invH[l], rr[1]);
-          }
         }
+      if constexpr (FUSED) {
+        const float *rrow = ref + b * ref_batch_stride + (long long)qi * (L * 2);
+#pragma unroll
+        for (int l = 0; l < L; ++l) nr[l] = *reinterpret_cast<const f32x2 *>(rrow + 2 * l);
+      }
+    };
+    issue_points(recs[0], qidx[0]);
+    __syncthreads();                                               // (2) windows staged
+    stamp(4);
+
+    const ST *vlane = vimg + c * VEC;                               // + lane's channel slice (global path)
+    const unsigned char *pool_lane = pool + c * 16;
+    auto finish_points = [&]() {
+      if constexpr (FUSED) {
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+          for (int k = 0; k < PPL; ++k) {
+            nx[l][k] = fmaf(nx[l][k], invW[l], nr[l][0]);
+            ny[l][k] = fmaf(ny[l][k], invH[l], nr[l][1]);
+          }
+      }
       if constexpr (FUSED) {   // softmax over the record's L*P logits: my points + DPP across the QL lanes
         float mx = -INFINITY;
 #pragma unroll
@@ -306,7 +322,7 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
           for (int k = 0; k < PPL; ++k) nw[l][k] *= inv;
       }
     };
-    load_points(recs[0], qidx[0]);
+    finish_points();
 
 #pragma unroll 1
     for (int s = 0; s < NS; ++s) {
@@ -330,7 +346,7 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
           sy[l][k] = ny[l][k];
           sw[l][k] = nw[l][k];
         }
-      if (s + 1 < NS) load_points(rec_next, q_next);
+      issue_points(rec_next, q_next);                              // (after the last slot: record 0, unused)
 
       f32x2 accp[4][VEC / 2];
 #pragma unroll
@@ -436,6 +452,14 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
         }
       }
 
+      // the next slot's front-end runs BEFORE this slot's store is issued: vmcnt is in order, so waiting for the point
+      // loads after the store would also wait for the store to reach memory (that wait sat in the loop latch)
+      finish_points();
+      // (pin the results here: hipcc otherwise sinks half of the arithmetic, and its vmcnt(0), below the store)
+#pragma unroll
+      for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) asm volatile("" : "+v"(nx[l][k]), "+v"(ny[l][k]), "+v"(nw[l][k]));
       if (qvalid) {
         v16 o;
 #pragma unroll
