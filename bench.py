@@ -98,14 +98,17 @@ def cpu_baseline(args, levels_hw):
 
 def traffic_from_profile(args):
     """HBM bytes per launch of the MSDeformAttn kernel from the PMC passes committed under profiles/ (collected with
-    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE ...` around this very script; bench.py cannot read counters
-    itself).  Only reported when the committed measurement is for this workload; raw counter bytes, see the file's note
-    on FETCH_SIZE calibration."""
+    `rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum` and `--pmc TCC_EA0_WRREQ_*` in separate passes around this very
+    script, tools/pmc_bench_traffic.sh; bench.py cannot read counters itself).  Only reported when the committed
+    measurement is for this workload."""
     path = os.path.join(ROOT, "profiles", "r01_msda_traffic_batch%d.json" % args.batch)
     try:
         with open(path) as f:
             t = json.load(f)
         if t.get("batch") == args.batch and t.get("levels") == args.levels and args.image == 512:
+            if "hbm_bytes" in t:      # memory-side requests by size (32/64/128 B): no FETCH_SIZE calibration needed
+                return {"bytes": t["hbm_bytes"], "read_bytes": t["hbm_read_bytes"], "write_bytes": t["hbm_write_bytes"],
+                        "source": os.path.relpath(path, ROOT)}
             return {"bytes": t["hbm_bytes_raw"], "bytes_if_fetch_doubled": t["hbm_bytes_fetch_doubled"],
                     "source": os.path.relpath(path, ROOT)}
     except (OSError, ValueError, KeyError):

@@ -47,6 +47,22 @@ rec = {
 }
 for k, v in mean.items():
     rec[k + ("_KB" if k.endswith("_SIZE") else "")] = v
+if "TCC_EA0_RDREQ_128B_sum" in mean:
+    # memory-side requests by size: the calibration MI355X_MICROARCH.md asks for ("calibrate on a known byte count in your
+    # own access pattern"): on this kernel every read request is a 128-B line, so FETCH_SIZE (requests x 64 B) is half
+    rd = 128.0 * mean["TCC_EA0_RDREQ_128B_sum"] + 64.0 * mean.get("TCC_EA0_RDREQ_64B_sum", 0.0) + \
+        32.0 * mean.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+    wr64 = mean.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+    wr = 64.0 * wr64 + 32.0 * (mean.get("TCC_EA0_WRREQ_sum", wr64) - wr64)
+    rec["hbm_read_bytes"] = rd
+    rec["hbm_write_bytes"] = wr
+    rec["hbm_bytes"] = rd + wr
+    rec["method"] = ("rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum "
+                     "(own pass) and --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum ... (own pass) around bench.py; "
+                     "bytes = sum over request sizes; per-launch means over %s dispatches" % {k: len(v) for k, v in vals.items()})
+    rec["note"] = ("L2 memory-side (fabric) requests: Infinity-Cache hits are included, so this is the traffic the L2 sends "
+                   "out, an upper bound on DRAM traffic.  FETCH_SIZE of the same launches reads half of hbm_read_bytes "
+                   "(gfx950: 128-B requests tallied at 64 B).")
 if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
     rec["hbm_bytes_raw"] = (mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024.0
     rec["hbm_bytes_fetch_doubled"] = (2 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024.0
