@@ -121,6 +121,7 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
     b = bt / T_img;
 
     // ---- this lane's NS queries (record index or -1) -----------------------------------------------------------
+    int qdup[NS];                                 // pre-pass only: q, or a valid query of the tile when q is past the edge
     {
       int Hq = Hs[0], Wq = Ws[0], Sq = St[0], tb = 0;
       if (pyramid) {
@@ -139,9 +140,11 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
           const int qy = ty * THT + s * SH + j / TW, qx = tx * TW + (j % TW);
           ok = qy < Hq && qx < Wq;
           q = Sq + qy * Wq + qx;
+          qdup[s] = Sq + min(qy, Hq - 1) * Wq + min(qx, Wq - 1);
         } else {
           q = (t * NS + s) * TQ + j;
           ok = q < Lq;
+          qdup[s] = min(q, Lq - 1);
         }
         recs[s] = ok ? ((long long)b * Lq + q) * M + m : -1;
         qidx[s] = ok ? q : 0;
@@ -153,8 +156,10 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
       f32x2 pxy[NS][L][PPL];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const float *lrec = loc + (recs[s] < 0 ? 0 : recs[s]) * (L * P * 2) + c * 2;
-        const float *rrow = FUSED ? ref + b * ref_batch_stride + (long long)qidx[s] * (L * 2) : nullptr;
+        // a lane past the tile's edge repeats a valid query of the tile: it cannot move the box, and nothing below
+        // has to exclude it
+        const float *lrec = loc + (((long long)b * Lq + qdup[s]) * M + m) * (L * P * 2) + c * 2;
+        const float *rrow = FUSED ? ref + b * ref_batch_stride + (long long)qdup[s] * (L * 2) : nullptr;
 #pragma unroll
         for (int l = 0; l < L; ++l)
 #pragma unroll
@@ -169,19 +174,27 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
       }
 #pragma unroll
       for (int l = 0; l < L; ++l) {
-        unsigned lo = 0xFFFFFFFFu, hi = 0u;
+        // Box of the FIRST corner (x0, y0) = floor(w_im, h_im) over the lane's points, on floats: floor is monotone, so
+        // min/max commute with it and one floor per lane and level replaces one per point.  A sample is gated in iff
+        // -1 < w_im < W (and likewise h): clamping to [-1, W - 0.5] maps every gated-out coordinate onto a value a
+        // gated-in sample could have, so such samples can only widen the box towards the map border, never past the
+        // 1-pixel apron (NaN clamps to -1).  Same expression as the gather's, so both sides floor the same number.
+        float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
           for (int k = 0; k < PPL; ++k) {
             const float h_im = pxy[s][l][k][1] * Hs[l] - 0.5f, w_im = pxy[s][l][k][0] * Ws[l] - 0.5f;
-            const bool gate = recs[s] >= 0 && h_im > -1 && w_im > -1 && h_im < Hs[l] && w_im < Ws[l];
-            // gate => x0 in [-1, W-1], y0 in [-1, H-1]; biased by +1 to stay unsigned; the box covers all four
-            // corners INCLUDING out-of-map ones (staged as zeros)
-            const unsigned xa = (unsigned)((int)floorf(w_im) + 1), ya = (unsigned)((int)floorf(h_im) + 1);
-            lo = gate ? pk_min(lo, xa | (ya << 16)) : lo;
-            hi = gate ? pk_max(hi, (xa + 1) | ((ya + 1) << 16)) : hi;
+            const float wc = __builtin_amdgcn_fmed3f(w_im, -1.f, (float)Ws[l] - 0.5f);
+            const float hc = __builtin_amdgcn_fmed3f(h_im, -1.f, (float)Hs[l] - 0.5f);
+            mnx = fminf(mnx, wc);
+            mxx = fmaxf(mxx, wc);
+            mny = fminf(mny, hc);
+            mxy = fmaxf(mxy, hc);
           }
+        // biased by +1 to stay unsigned: x0 in [-1, W-1] -> [0, W]; the box covers x0 .. x0 + 1
+        unsigned lo = (unsigned)((int)floorf(mnx) + 1) | ((unsigned)((int)floorf(mny) + 1) << 16);
+        unsigned hi = (unsigned)((int)floorf(mxx) + 2) | ((unsigned)((int)floorf(mxy) + 2) << 16);
         lo = wave_reduce_pk<true>(lo);
         hi = wave_reduce_pk<false>(hi);
         if ((tid & 63) == 0) {
