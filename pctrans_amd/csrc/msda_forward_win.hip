@@ -112,15 +112,17 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
   // right after the gather of item i, into the other half of `bb`, so the waves that finish their gather early spend
   // the wait on the next item's point loads instead of idling at a third barrier.
   int m = 0, b = 0;
-  long long recs[NS];
-  int qidx[NS];                                                     // query index within the image (FUSED: ref row)
+  // this lane's NS queries: slot s is query q0 + s * dq of image b (dq uniform), valid iff bit s of okmask; the record
+  // index ((b * Lq + q) * M + m) is formed where it is used (one 64-bit mad on a uniform base)
+  int q0 = 0, dq = 0;
+  unsigned okmask = 0;
   auto prepass = [&](const int item, unsigned *bbw) {
     m = item % M;
     const int bt = item / M;
     const int t = bt % T_img;
     b = bt / T_img;
 
-    // ---- this lane's NS queries (record index or -1) -----------------------------------------------------------
+    // ---- this lane's NS queries ----------------------------------------------------------------------------------
     int qdup[NS];                                 // pre-pass only: q, or a valid query of the tile when q is past the edge
     {
       int Hq = Hs[0], Wq = Ws[0], Sq = St[0], tb = 0;
@@ -132,6 +134,8 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
       const int tpr = (Wq + TW - 1) / TW;
       const int tl = t - tb;
       const int ty = tl / tpr, tx = tl - ty * tpr;
+      okmask = 0;
+      dq = pyramid ? SH * Wq : TQ;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         int q;
@@ -146,8 +150,8 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
           ok = q < Lq;
           qdup[s] = min(q, Lq - 1);
         }
-        recs[s] = ok ? ((long long)b * Lq + q) * M + m : -1;
-        qidx[s] = ok ? q : 0;
+        okmask |= ok ? 1u << s : 0u;
+        if (s == 0) q0 = q;
       }
     }
 
@@ -275,8 +279,9 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
     // began with a full memory round trip: `s_waitcnt vmcnt(0)` directly after the ten loads.) -------------------------
     float nx[L][PPL], ny[L][PPL], nw[L][PPL];
     f32x2 nr[FUSED ? L : 1];
-    auto issue_points = [&](long long rec, int qi) {
-      const long long r = rec < 0 ? 0 : rec;
+    const long long rec_base = (long long)b * Lq * M + m;          // uniform
+    auto issue_points = [&](int qi) {                               // qi: a valid query of image b
+      const long long r = rec_base + (long long)qi * M;
       const float *lrec = loc + r * (L * P * 2) + c * 2;
       const float *wrec = attn + r * (L * P) + c;
 #pragma unroll
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
         for (int l = 0; l < L; ++l) nr[l] = *reinterpret_cast<const f32x2 *>(rrow + 2 * l);
       }
     };
-    issue_points(recs[0], qidx[0]);
+    issue_points((okmask & 1u) ? q0 : 0);
     __syncthreads();                                               // (2) windows staged
     stamp(4);
 
@@ -339,17 +344,9 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
 
 #pragma unroll 1
     for (int s = 0; s < NS; ++s) {
-      long long rec = recs[0];
-#pragma unroll
-      for (int u = 1; u < NS; ++u) rec = s == u ? recs[u] : rec;
-      long long rec_next = -1;
-      int q_next = 0;
-#pragma unroll
-      for (int u = 1; u < NS; ++u) {
-        rec_next = s + 1 == u ? recs[u] : rec_next;
-        q_next = s + 1 == u ? qidx[u] : q_next;
-      }
-      const bool qvalid = rec >= 0;
+      const bool qvalid = (okmask >> s) & 1u;
+      const long long rec = rec_base + (long long)(q0 + s * dq) * M;          // used only when qvalid
+      const int q_next = ((okmask >> (s + 1)) & 1u) ? q0 + (s + 1) * dq : 0;   // past the last slot: query 0, unused
       float sx[L][PPL], sy[L][PPL], sw[L][PPL];
 #pragma unroll
       for (int l = 0; l < L; ++l)
@@ -359,7 +356,7 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
           sy[l][k] = ny[l][k];
           sw[l][k] = nw[l][k];
         }
-      issue_points(rec_next, q_next);                              // (after the last slot: record 0, unused)
+      issue_points(q_next);
 
       f32x2 accp[4][VEC / 2];
 #pragma unroll
