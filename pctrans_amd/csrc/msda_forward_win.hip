@@ -116,6 +116,13 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
   // index ((b * Lq + q) * M + m) is formed where it is used (one 64-bit mad on a uniform base)
   int q0 = 0, dq = 0;
   unsigned okmask = 0;
+  // the item's sampling locations (FUSED: already ref + offset / (W, H)), loaded ONCE by the box pre-pass and carried in
+  // registers to the gather -- the gather used to read sampling_locations a second time, 29 us later and long out of L2
+  // (1.43 GB per launch at batch 64, a sixth of the kernel's traffic).  Only while the item's locations fit 32 VGPRs
+  // (NS * L * PPL pairs) under the 168-VGPR budget of the 16 x 16 tile; the other geometries reload them per slot as
+  // before (CARRY = false: lxy dies with the pre-pass).
+  constexpr bool CARRY = NS == 4 && P == 4 && NS * L * PPL * 2 <= 32;
+  f32x2 lxy[NS][L][PPL];
   auto prepass = [&](const int item, unsigned *bbw) {
     m = item % M;
     const int bt = item / M;
@@ -157,7 +164,6 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
 
     // ---- pre-pass: per-level bounding box (incl. 1-pixel apron) of every corner the tile touches ---------------
     {
-      f32x2 pxy[NS][L][PPL];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         // a lane past the tile's edge repeats a valid query of the tile: it cannot move the box, and nothing below
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
               const f32x2 r = *reinterpret_cast<const f32x2 *>(rrow + 2 * l);
               v = f32x2{fmaf(v[0], invW[l], r[0]), fmaf(v[1], invH[l], r[1])};
             }
-            pxy[s][l][k] = v;
+            lxy[s][l][k] = v;
           }
       }
 #pragma unroll
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
         for (int s = 0; s < NS; ++s)
 #pragma unroll
           for (int k = 0; k < PPL; ++k) {
-            const float h_im = pxy[s][l][k][1] * Hs[l] - 0.5f, w_im = pxy[s][l][k][0] * Ws[l] - 0.5f;
+            const float h_im = lxy[s][l][k][1] * Hs[l] - 0.5f, w_im = lxy[s][l][k][0] * Ws[l] - 0.5f;
             const float wc = __builtin_amdgcn_fmed3f(w_im, -1.f, (float)Ws[l] - 0.5f);
             const float hc = __builtin_amdgcn_fmed3f(h_im, -1.f, (float)Hs[l] - 0.5f);
             mnx = fminf(mnx, wc);
@@ -272,31 +278,35 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
       }
     }
     stamp(3);
-    // ---- gather, one slot after the other.  A slot's points (and, FUSED, its reference points) are only ISSUED here;
-    // the front-end arithmetic that consumes them runs a whole slot later (`finish_points`), so the wave never sits
-    // on a fresh load: the first slot's loads are in flight across barrier (2) together with the LDS-DMA pieces, slot
-    // s+1's during slot s's gather.  (With the arithmetic right behind the loads -- the first version -- every slot
-    // began with a full memory round trip: `s_waitcnt vmcnt(0)` directly after the ten loads.) -------------------------
+    // ---- gather, one slot after the other.  Locations come from the registers the pre-pass filled; a slot's attention
+    // weights (FUSED: logits) are only ISSUED here and consumed a whole slot later (`finish_points`), so the wave never
+    // sits on a fresh load: the first slot's are in flight across barrier (2) together with the LDS-DMA pieces, slot
+    // s+1's during slot s's gather. ------------------------------------------------------------------------------------
     float nx[L][PPL], ny[L][PPL], nw[L][PPL];
-    f32x2 nr[FUSED ? L : 1];
+    f32x2 nr[(FUSED && !CARRY) ? L : 1];
     const long long rec_base = (long long)b * Lq * M + m;          // uniform
     auto issue_points = [&](int qi) {                               // qi: a valid query of image b
       const long long r = rec_base + (long long)qi * M;
-      const float *lrec = loc + r * (L * P * 2) + c * 2;
       const float *wrec = attn + r * (L * P) + c;
 #pragma unroll
       for (int l = 0; l < L; ++l)
 #pragma unroll
-        for (int k = 0; k < PPL; ++k) {
-          const f32x2 xy = *reinterpret_cast<const f32x2 *>(lrec + (l * P + k * QL) * 2);
-          nx[l][k] = xy[0];
-          ny[l][k] = xy[1];
-          nw[l][k] = wrec[l * P + k * QL];
-        }
-      if constexpr (FUSED) {
-        const float *rrow = ref + b * ref_batch_stride + (long long)qi * (L * 2);
+        for (int k = 0; k < PPL; ++k) nw[l][k] = wrec[l * P + k * QL];
+      if constexpr (!CARRY) {
+        const float *lrec = loc + r * (L * P * 2) + c * 2;
 #pragma unroll
-        for (int l = 0; l < L; ++l) nr[l] = *reinterpret_cast<const f32x2 *>(rrow + 2 * l);
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+          for (int k = 0; k < PPL; ++k) {
+            const f32x2 xy = *reinterpret_cast<const f32x2 *>(lrec + (l * P + k * QL) * 2);
+            nx[l][k] = xy[0];
+            ny[l][k] = xy[1];
+          }
+        if constexpr (FUSED) {
+          const float *rrow = ref + b * ref_batch_stride + (long long)qi * (L * 2);
+#pragma unroll
+          for (int l = 0; l < L; ++l) nr[l] = *reinterpret_cast<const f32x2 *>(rrow + 2 * l);
+        }
       }
     };
     issue_points((okmask & 1u) ? q0 : 0);
@@ -305,16 +315,29 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
 
     const ST *vlane = vimg + c * VEC;                               // + lane's channel slice (global path)
     const unsigned char *pool_lane = pool + c * 16;
-    auto finish_points = [&]() {
-      if constexpr (FUSED) {
+    auto finish_points = [&](const int sn) {                        // sn (uniform): the slot being prepared
+      if constexpr (!CARRY) {
+        if constexpr (FUSED) {
 #pragma unroll
-        for (int l = 0; l < L; ++l)
+          for (int l = 0; l < L; ++l)
 #pragma unroll
-          for (int k = 0; k < PPL; ++k) {
-            nx[l][k] = fmaf(nx[l][k], invW[l], nr[l][0]);
-            ny[l][k] = fmaf(ny[l][k], invH[l], nr[l][1]);
-          }
-      }
+            for (int k = 0; k < PPL; ++k) {
+              nx[l][k] = fmaf(nx[l][k], invW[l], nr[l][0]);
+              ny[l][k] = fmaf(ny[l][k], invH[l], nr[l][1]);
+            }
+        }
+      } else
+      [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
+        ((sn == Ss ? (void)[&] {
+#pragma unroll
+          for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) {
+              nx[l][k] = lxy[Ss][l][k][0];
+              ny[l][k] = lxy[Ss][l][k][1];
+            }
+        }() : (void)0), ...);
+      }(std::make_integer_sequence<int, NS>{});
       if constexpr (FUSED) {   // softmax over the record's L*P logits: my points + DPP across the QL lanes
         float mx = -INFINITY;
 #pragma unroll
@@ -340,7 +363,7 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
           for (int k = 0; k < PPL; ++k) nw[l][k] *= inv;
       }
     };
-    finish_points();
+    finish_points(0);
 
 #pragma unroll 1
     for (int s = 0; s < NS; ++s) {
@@ -464,7 +487,7 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
 
       // the next slot's front-end runs BEFORE this slot's store is issued: vmcnt is in order, so waiting for the point
       // loads after the store would also wait for the store to reach memory (that wait sat in the loop latch)
-      finish_points();
+      finish_points(s + 1);
       // (pin the results here: hipcc otherwise sinks half of the arithmetic, and its vmcnt(0), below the store)
 #pragma unroll
       for (int l = 0; l < L; ++l)
