@@ -24,6 +24,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <utility>
 
 #include "msda_win_common.hpp"
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
     const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn, const int N,
     const int S, const int M, const int Lq, const int pyramid, const int pool_px,
     typename Traits<T>::store_t *__restrict__ out, const float *__restrict__ ref, const long long ref_batch_stride,
-    unsigned long long *__restrict__ stamps = nullptr)
+    unsigned *__restrict__ queue, unsigned long long *__restrict__ stamps = nullptr)
 {
   using ST = typename Traits<T>::store_t;
   constexpr int VEC = 16 / (int)sizeof(ST);       // channels per lane
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char *pool = smem_raw;                                   // the level windows (head-pixels of PXB bytes)
-  unsigned *bb = reinterpret_cast<unsigned *>(smem_raw + (size_t)pool_px * PXB);   // [4 waves][L][2]
+  unsigned *bb = reinterpret_cast<unsigned *>(smem_raw + (size_t)pool_px * PXB);   // [2][4 waves][L][2]
+  unsigned *next_idx = bb + 2 * (WIN_BLOCK / 64) * WIN_MAXL * 2;                    // the workgroup's next item (index in the chunk)
 
   const int tid = threadIdx.x, wave = tid >> 6;
   const int c = tid & (QL - 1);                   // lane within the query's group
@@ -220,15 +222,27 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
   };
 
   constexpr int BB_HALF = (WIN_BLOCK / 64) * WIN_MAXL * 2;
+  // Items are handed out dynamically inside an XCD's chunk: the first round is static (workgroup slot), every further
+  // item is nslots + the XCD's counter (`queue[xcd]`, zero between launches), fetched one item ahead by one lane and
+  // passed through LDS.  Every processed item costs exactly one fetch, so the fetch that returns n_x - 1 (n_x = items
+  // of this XCD) is the launch's last one and puts the counter back to zero: no per-launch memset, graph-replay safe.  With the static stride the 8 heads of a tile -- which share every 128-B line of the tile's windows,
+  // two heads per line -- drifted apart by more than the ~6 us a line survives in the 4 MB L2 at this kernel's
+  // traffic, so each head fetched the lines again; the counter starts the heads of a tile within ~2 us of each other.
   int item = xcd * chunk + slot0;
   int par = 0;
   stamp(-1);
   if (item < item_end) prepass(item, bb);
-  for (; item < item_end; item += nslots) {
+  while (item < item_end) {
     const unsigned *bbr = bb + par * BB_HALF;
     stamp(0);
     __syncthreads();                                               // (A) boxes visible; pool free
     stamp(1);
+    unsigned fetched = (unsigned)(item - xcd * chunk + nslots);     // static stride when there is no queue
+    if (queue && tid == 0) {
+      const unsigned r = atomicAdd(queue + xcd, 1u);
+      if (r + 1u >= (unsigned)(item_end - xcd * chunk)) atomicExch(queue + xcd, 0u);
+      fetched = (unsigned)nslots + r;
+    }
 
     // ---- windows (identical in every lane; kept in SGPRs) -------------------------------------------------------
     int wx0[L], wy0[L], wwid[L], wbase[L], wsize[L], in_lds[L];
@@ -310,7 +324,8 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
       }
     };
     issue_points((okmask & 1u) ? q0 : 0);
-    __syncthreads();                                               // (2) windows staged
+    if (tid == 0) next_idx[0] = fetched;
+    __syncthreads();                                               // (2) windows staged; next item known
     stamp(4);
 
     const ST *vlane = vimg + c * VEC;                               // + lane's channel slice (global path)
@@ -506,13 +521,44 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
     }
     stamp(5);
     par ^= 1;
-    if (item + nslots < item_end) prepass(item + nslots, bb + par * BB_HALF);
+    {                                                               // (written before barrier (2) of this item)
+      const unsigned nxt = __builtin_amdgcn_readfirstlane(next_idx[0]);
+      item = nxt < (unsigned)(item_end - xcd * chunk) ? xcd * chunk + (int)nxt : item_end;   // never out of the chunk
+    }
+    if (item < item_end) prepass(item, bb + par * BB_HALF);
     stamp(6);
   }
   if constexpr (STAMP) {
     if (tid == 0 && stamps)
       for (int i = 0; i < 8; ++i) stamps[(size_t)blockIdx.x * 8 + i] = t_sum[i];
   }
+}
+
+// One set of 8 per-XCD item counters per launch, from a small per-device ring zeroed once at allocation (the kernel
+// leaves every counter at zero again, see its item loop).  Launches on one stream are ordered; 256 launches may be in
+// flight across streams before a set is reused.  Returns nullptr (static item stride) when the ring cannot be
+// allocated -- e.g. the very first launch of the process happening under stream capture -- or with PCT_WIN_QUEUE=0.
+static unsigned *win_queue_slot()
+{
+  static const bool enabled = [] { const char *e = getenv("PCT_WIN_QUEUE"); return !(e && e[0] == '0'); }();
+  if (!enabled) return nullptr;
+  constexpr int MAX_DEV = 64, RING = 256;
+  static std::mutex mu;
+  static unsigned *ring[MAX_DEV] = {};
+  static unsigned seq[MAX_DEV] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ring[dev]) {
+    void *p = nullptr;
+    if (hipMalloc(&p, RING * 8 * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, RING * 8 * sizeof(unsigned)) != hipSuccess) {
+      (void)hipGetLastError();
+      if (p) (void)hipFree(p);
+      return nullptr;
+    }
+    ring[dev] = static_cast<unsigned *>(p);
+  }
+  return ring[dev] + 8 * (seq[dev]++ % RING);
 }
 
 static unsigned long long *g_stamp_buffer = nullptr;
@@ -538,23 +584,24 @@ int launch_msda_forward_win(const void *value, const int64_t *shapes, const int6
   const int NS = P == 8 ? (sizeof(ST) == 2 ? 1 : 2) : ((ns_env == 1 || ns_env == 2) ? ns_env : 4);   // 16-bit: 128 queries per slot
   const int pool_bytes = P == 8 ? 50 * 1024 : (NS == 1 ? 28 * 1024 : (NS == 2 ? 36 * 1024 : 50 * 1024));
   const int pool_px = pool_bytes / (QL * 16);
-  const size_t lds = (size_t)pool_px * QL * 16 + 2 * (WIN_BLOCK / 64) * WIN_MAXL * 2 * sizeof(unsigned);
+  const size_t lds = (size_t)pool_px * QL * 16 + 2 * (WIN_BLOCK / 64) * WIN_MAXL * 2 * sizeof(unsigned) + 16;
   const int pyramid = Lq == S ? 1 : 0;
   const int wg_per_cu = (NS == 4 || P == 8) ? 3 : 4;
   const dim3 grid(256 * wg_per_cu), block(WIN_BLOCK);
+  unsigned *queue = win_queue_slot();                              // nullptr: static item stride
   const ST *v = static_cast<const ST *>(value);
   const float *lc = static_cast<const float *>(loc), *at = static_cast<const float *>(attn);
   ST *o = static_cast<ST *>(out);
   if constexpr (sizeof(ST) == 4) {
     if (g_stamp_buffer && !ref && L == 4 && NS == 4) {   // diagnostic build: per-phase cycle stamps (tools/stamp_msda.py)
       hipLaunchKernelGGL((msda_forward_win_kernel<T, 16, 4, 4, 4, false, true>), grid, block, lds, stream, v, shapes,
-                         starts, lc, at, N, S, M, Lq, pyramid, pool_px, o, ref, ref_batch_stride, g_stamp_buffer);
+                         starts, lc, at, N, S, M, Lq, pyramid, pool_px, o, ref, ref_batch_stride, queue, g_stamp_buffer);
       return (int)hipGetLastError();
     }
   }
 #define PCT_WINP(L_, P_, NS_, FU_)                                                                                    \
   hipLaunchKernelGGL((msda_forward_win_kernel<T, 16, L_, P_, NS_, FU_>), grid, block, lds, stream, v, shapes, starts, \
-                     lc, at, N, S, M, Lq, pyramid, pool_px, o, ref, ref_batch_stride, nullptr)
+                     lc, at, N, S, M, Lq, pyramid, pool_px, o, ref, ref_batch_stride, queue, nullptr)
 #define PCT_WIN(L_, NS_, FU_) PCT_WINP(L_, 4, NS_, FU_)
   if (P == 8) {
     constexpr int NS8 = sizeof(ST) == 2 ? 1 : 2;
