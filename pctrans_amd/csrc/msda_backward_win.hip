@@ -41,7 +41,7 @@ __global__ __launch_bounds__(WIN_BLOCK, 2) void msda_backward_win_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn, const int N,
     const int S, const int M, const int Lq, const int pyramid, float *__restrict__ grad_value,
-    float *__restrict__ grad_loc, float *__restrict__ grad_attn)
+    float *__restrict__ grad_loc, float *__restrict__ grad_attn, unsigned *__restrict__ queue)
 {
   constexpr int D = 16, P = 4, VEC = 4, QL = 4;
   constexpr int TQ = WIN_BLOCK / QL;              // queries per slot (64)
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(WIN_BLOCK, 2) void msda_backward_win_kernel(
   int *gpool = reinterpret_cast<int *>(smem_raw + gofs);           // fixed-point accumulators (see `scale` below)
   unsigned *bb = reinterpret_cast<unsigned *>(smem_raw + 2 * (size_t)gofs);   // [4 waves][L][2]
   unsigned *mx = bb + (WIN_BLOCK / 64) * WIN_MAXL * 2;              // [4 waves][2]: max |grad_out| bits, max |attn| bits
+  unsigned *next_idx = mx + (WIN_BLOCK / 64) * 2;                   // the workgroup's next item (index in the XCD's chunk)
 
   const int tid = threadIdx.x, wave = tid >> 6;
   const int c = tid & (QL - 1);
@@ -90,7 +91,15 @@ __global__ __launch_bounds__(WIN_BLOCK, 2) void msda_backward_win_kernel(
   const int chunk = (items + 7) / 8;
   const int item_end = min((xcd + 1) * chunk, items);
 
-  for (int item = xcd * chunk + slot0; item < item_end; item += nslots) {
+  // items: first round static, then from the XCD's self-resetting counter (msda_win_common.hpp: win_queue_slot)
+  int item = xcd * chunk + slot0;
+  while (item < item_end) {
+    unsigned fetched = (unsigned)(item - xcd * chunk + nslots);     // static stride when there is no queue
+    if (queue && tid == 0) {
+      const unsigned r = atomicAdd(queue + xcd, 1u);
+      if (r + 1u >= (unsigned)(item_end - xcd * chunk)) atomicExch(queue + xcd, 0u);
+      fetched = (unsigned)nslots + r;
+    }
     const int m = item % M;
     const int bt = item / M;
     const int t = bt % T_img;
@@ -177,7 +186,13 @@ __global__ __launch_bounds__(WIN_BLOCK, 2) void msda_backward_win_kernel(
         }
       }
     }
+    if (tid == 0) next_idx[0] = fetched;
     __syncthreads();                                               // (1) boxes visible; previous item's flush done
+    int next_item;
+    {
+      const unsigned nxt = __builtin_amdgcn_readfirstlane(next_idx[0]);   // (rewritten only after everyone passed (2))
+      next_item = nxt < (unsigned)(item_end - xcd * chunk) ? xcd * chunk + (int)nxt : item_end;
+    }
 
     // ---- fixed-point scale of the LDS accumulators ------------------------------------------------------------
     // A window dword receives at most NS*64*P <= 512 contributions w_corner * attn * grad_out, each bounded by
@@ -520,6 +535,7 @@ __global__ __launch_bounds__(WIN_BLOCK, 2) void msda_backward_win_kernel(
       }
     }
     // no barrier here: the next item's barrier (1) orders this flush before its windows are zeroed
+    item = next_item;
   }
 }
 
@@ -536,14 +552,15 @@ int launch_msda_backward_win(const float *value, const int64_t *shapes, const in
   static const int ns_env = [] { const char *e = getenv("PCT_BWD_NS"); return e ? atoi(e) : 2; }();
   const int NS = ns_env == 1 ? 1 : 2;
   const int pool_px = bwd_win_pool_px(NS);                           // value pool + grad pool + boxes per workgroup
-  const size_t lds = 2 * (size_t)pool_px * 64 + (WIN_BLOCK / 64) * (WIN_MAXL + 1) * 2 * sizeof(unsigned);
+  const size_t lds = 2 * (size_t)pool_px * 64 + (WIN_BLOCK / 64) * (WIN_MAXL + 1) * 2 * sizeof(unsigned) + 16;
   const int wg_fit = (int)((160 * 1024) / lds);
   const int wg_per_cu = wg_fit < 1 ? 1 : (wg_fit > 3 ? 3 : wg_fit);
   const int pyramid = Lq == S ? 1 : 0;
   const dim3 grid(256 * wg_per_cu), block(WIN_BLOCK);
+  unsigned *queue = win_queue_slot();                              // nullptr: static item stride
 #define PCT_BWIN(L_, NS_)                                                                                          \
   hipLaunchKernelGGL((msda_backward_win_kernel<L_, NS_>), grid, block, lds, stream, grad_out, value, shapes, starts, \
-                     loc, attn, N, S, M, Lq, pyramid, grad_value, grad_loc, grad_attn)
+                     loc, attn, N, S, M, Lq, pyramid, grad_value, grad_loc, grad_attn, queue)
 #define PCT_BWIN_L(NS_)              \
   if (L == 3) PCT_BWIN(3, NS_);      \
   else if (L == 4) PCT_BWIN(4, NS_); \

@@ -538,7 +538,7 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
 // leaves every counter at zero again, see its item loop).  Launches on one stream are ordered; 256 launches may be in
 // flight across streams before a set is reused.  Returns nullptr (static item stride) when the ring cannot be
 // allocated -- e.g. the very first launch of the process happening under stream capture -- or with PCT_WIN_QUEUE=0.
-static unsigned *win_queue_slot()
+unsigned *win_queue_slot()
 {
   static const bool enabled = [] { const char *e = getenv("PCT_WIN_QUEUE"); return !(e && e[0] == '0'); }();
   if (!enabled) return nullptr;

@@ -78,6 +78,12 @@ __device__ __forceinline__ unsigned wave_reduce_umax(unsigned v)
   return max(max(r0, r1), max(r2, r3));
 }
 
+// A set of 8 zeroed per-XCD work-item counters for one launch of a persistent windowed kernel (defined in
+// msda_forward_win.hip; nullptr = use the static item stride).  Protocol inside the kernels: the first round of items is
+// static (workgroup slot), every further item of XCD x is nslots + atomicAdd(queue + x, 1); every processed item costs
+// exactly one fetch, so the fetch that returns n_x - 1 is the launch's last one and zeroes the counter again.
+unsigned *win_queue_slot();
+
 // One level's window, derived identically by every lane from the 4 per-wave boxes in LDS.
 struct LevelWindow {
   int x0, y0, wid, size;   // origin, width (pixels), pixel count (0 = no gated sample on this level)
