@@ -527,3 +527,29 @@ def test_fullsize_forward_replays_from_a_hip_graph(MSDA):
         assert torch.equal(out, eager) and torch.equal(out2, eager)
     # and eager launches interleaved with replays still agree
     assert torch.equal(MSDA.ms_deform_attn_forward(v, sh, st, loc, attn, 64), eager)
+
+
+def test_static_item_stride_path_matches(MSDA):
+    """PCT_WIN_QUEUE=0 (also the fallback when the counter ring cannot be allocated): same results from the static stride."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from msda_cases import make_case\n"
+        "from pctrans_amd import MultiScaleDeformableAttention as MSDA\n"
+        "import oracle.msda_oracle as orc\n"
+        "c = make_case(seed=5, model_like=True, Lq=5376, N=4, M=8, D=16, P=4, shapes=[(16, 16), (32, 32), (64, 64)])\n"
+        "d = lambda a: torch.from_numpy(a).cuda()\n"
+        "args = [d(c[k]) for k in ('value', 'shapes', 'starts', 'loc', 'attn')]\n"
+        "out = MSDA.ms_deform_attn_forward(*args, 64)\n"
+        "want = orc.forward(c['value'], c['shapes'], c['starts'], c['loc'], c['attn'])\n"
+        "assert abs(out.cpu().numpy() - want).max() < 2e-5\n"
+        "go = torch.randn_like(out)\n"
+        "gv, gl, ga = MSDA.ms_deform_attn_backward(*args, go, 64)\n"
+        "rv, rl, ra = orc.backward(c['value'], c['shapes'], c['starts'], c['loc'], c['attn'], go.cpu().numpy())\n"
+        "assert abs(gv.cpu().numpy() - rv).max() < 1e-4 and abs(ga.cpu().numpy() - ra).max() < 1e-4\n"
+        "print('ok')\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, PCT_WIN_QUEUE="0")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stderr[-2000:]
