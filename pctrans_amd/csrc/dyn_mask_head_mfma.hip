@@ -26,10 +26,24 @@ typedef float dm_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int DMM_PT = 8;        // pixel tiles (16 px each) per wave
 constexpr int DMM_BLOCK = 256;
 
+typedef float dm_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 dm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned dm_u32x2 __attribute__((ext_vector_type(2)));
+
+// two v_cvt_pk_bf16_f32 (round to nearest even), no per-element conversions and byte permutes
 __device__ __forceinline__ dm_s16x4 pack_bf16x4(float a, float b, float c, float d)
 {
-  const dm_bf16x4 v = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+  const dm_u32x2 v = {__builtin_bit_cast(unsigned, __builtin_convertvector(dm_f32x2{a, b}, dm_bf16x2)),
+                      __builtin_bit_cast(unsigned, __builtin_convertvector(dm_f32x2{c, d}, dm_bf16x2))};
   return __builtin_bit_cast(dm_s16x4, v);
+}
+
+// relu as ONE v_max_f32: fmaxf on an MFMA result makes hipcc emit a canonicalising v_max_f32 x, x, x first
+__device__ __forceinline__ float dm_relu(float x)
+{
+  float y;
+  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+  return y;
 }
 
 // feat [N, 16, H, W] fp32, ref [N, Q, 2], params [N, Q, G] fp32 (G = 233 with rel coords, 217 without),
@@ -114,12 +128,12 @@ __global__ __launch_bounds__(DMM_BLOCK) void dmh_logits_mfma_kernel(const float 
       for (int r = 0; r < 4; ++r) c0[r] = fmaf(wyv[r], rely, fmaf(wxv[r], relx, b0v[r]));
       c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, fb[t], c0, 0, 0, 0);
       // relu + bf16: accumulator rows 4g..4g+3 of pixel `col` == B operand k-slots 4g..4g+3 of column `col`
-      const dm_s16x4 xb = pack_bf16x4(fmaxf(c0[0], 0.f), fmaxf(c0[1], 0.f), fmaxf(c0[2], 0.f), fmaxf(c0[3], 0.f));
+      const dm_s16x4 xb = pack_bf16x4(dm_relu(c0[0]), dm_relu(c0[1]), dm_relu(c0[2]), dm_relu(c0[3]));
       dm_f32x4 c1 = {b1v[0], b1v[1], b1v[2], b1v[3]};
       c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, xb, c1, 0, 0, 0);
       float part = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) part = fmaf(w2v[r], fmaxf(c1[r], 0.f), part);
+      for (int r = 0; r < 4; ++r) part = fmaf(w2v[r], dm_relu(c1[r]), part);
       part += __shfl_xor(part, 16);                              // rows 4g..4g+3 (+) rows of the partner group
       const int px = px_base + t * 16 + col;
       if (writer && px < HW) lrow[px] = (__bf16)(part + b2);
