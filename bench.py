@@ -230,13 +230,13 @@ def main():
                           "operands as exact 3-way bf16 splits, 6 x v_mfma_f32_32x32x16_bf16 per fp32 MFMA-equivalent)" % rows)
                 note = ("achieved = bf16 MFMA flops executed (6 x the GEMM's 2*rows*128*1024) / launch time; peak = dense "
                         "bf16 MFMA rate; the same GEMM counted once is gemm_fp32_equiv_tflops (the fp32 MFMA peak is "
-                        "157.3); the step's other large GEMM (linear2, K = 1024) runs on hipBLASLt")
+                        "157.3); the step's other large GEMM (linear2 + residual + LayerNorm, K = 1024) is linear_ln_split.hip, "
+                        "same arithmetic")
             else:
                 tf, peak = gemm_tf, 157.3
                 kernel = ("pct::linear_k128_kernel<bias+ReLU> (encoder FFN linear1: [%d,128] x [1024,128]^T, fp32, "
                           "v_mfma_f32_32x32x2_f32)" % rows)
-                note = ("peak = dense fp32 MFMA rate (256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz); the step's other large "
-                        "GEMM (linear2, K = 1024) runs on hipBLASLt")
+                note = "peak = dense fp32 MFMA rate (256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz)"
             out["roofline_mfma"] = {
                 "kernel": kernel, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                 "gemm_fp32_equiv_tflops": gemm_tf, "mean_launch_ms": ms1, "launches_timed": len(ffn1),
