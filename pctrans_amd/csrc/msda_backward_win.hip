@@ -557,7 +557,7 @@ int launch_msda_backward_win(const float *value, const int64_t *shapes, const in
   const int wg_per_cu = wg_fit < 1 ? 1 : (wg_fit > 3 ? 3 : wg_fit);
   const int pyramid = Lq == S ? 1 : 0;
   const dim3 grid(256 * wg_per_cu), block(WIN_BLOCK);
-  unsigned *queue = win_queue_slot();                              // nullptr: static item stride
+  unsigned *queue = win_queue_slot(stream);                        // nullptr: static item stride
 #define PCT_BWIN(L_, NS_)                                                                                          \
   hipLaunchKernelGGL((msda_backward_win_kernel<L_, NS_>), grid, block, lds, stream, grad_out, value, shapes, starts, \
                      loc, attn, N, S, M, Lq, pyramid, grad_value, grad_loc, grad_attn, queue)

@@ -538,7 +538,7 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
 // leaves every counter at zero again, see its item loop).  Launches on one stream are ordered; 256 launches may be in
 // flight across streams before a set is reused.  Returns nullptr (static item stride) when the ring cannot be
 // allocated -- e.g. the very first launch of the process happening under stream capture -- or with PCT_WIN_QUEUE=0.
-unsigned *win_queue_slot()
+unsigned *win_queue_slot(hipStream_t stream)
 {
   static const bool enabled = [] { const char *e = getenv("PCT_WIN_QUEUE"); return !(e && e[0] == '0'); }();
   if (!enabled) return nullptr;
@@ -550,6 +550,12 @@ unsigned *win_queue_slot()
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
   if (!ring[dev]) {
+    // never allocate under stream capture (an allocation would invalidate the capture): static stride for this launch
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
     void *p = nullptr;
     if (hipMalloc(&p, RING * 8 * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, RING * 8 * sizeof(unsigned)) != hipSuccess) {
       (void)hipGetLastError();
@@ -588,7 +594,7 @@ int launch_msda_forward_win(const void *value, const int64_t *shapes, const int6
   const int pyramid = Lq == S ? 1 : 0;
   const int wg_per_cu = (NS == 4 || P == 8) ? 3 : 4;
   const dim3 grid(256 * wg_per_cu), block(WIN_BLOCK);
-  unsigned *queue = win_queue_slot();                              // nullptr: static item stride
+  unsigned *queue = win_queue_slot(stream);                        // nullptr: static item stride
   const ST *v = static_cast<const ST *>(value);
   const float *lc = static_cast<const float *>(loc), *at = static_cast<const float *>(attn);
   ST *o = static_cast<ST *>(out);

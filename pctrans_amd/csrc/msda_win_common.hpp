@@ -82,7 +82,7 @@ __device__ __forceinline__ unsigned wave_reduce_umax(unsigned v)
 // msda_forward_win.hip; nullptr = use the static item stride).  Protocol inside the kernels: the first round of items is
 // static (workgroup slot), every further item of XCD x is nslots + atomicAdd(queue + x, 1); every processed item costs
 // exactly one fetch, so the fetch that returns n_x - 1 is the launch's last one and zeroes the counter again.
-unsigned *win_queue_slot();
+unsigned *win_queue_slot(hipStream_t stream);
 
 // One level's window, derived identically by every lane from the 4 per-wave boxes in LDS.
 struct LevelWindow {
