@@ -557,7 +557,9 @@ unsigned *win_queue_slot(hipStream_t stream)
       return nullptr;
     }
     void *p = nullptr;
-    if (hipMalloc(&p, RING * 8 * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, RING * 8 * sizeof(unsigned)) != hipSuccess) {
+    // (the memset runs on the null stream; launches may come from non-blocking streams: wait for it once)
+    if (hipMalloc(&p, RING * 8 * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, RING * 8 * sizeof(unsigned)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
       (void)hipGetLastError();
       if (p) (void)hipFree(p);
       return nullptr;
