@@ -170,6 +170,19 @@ def test_linear_k128_split_products_keep_fp32_accuracy_over_the_exponent_range()
     assert err <= 2.0 * lib + 1e-8, (err, lib)
 
 
+def test_linear_k128_unaligned_bias_takes_the_fp32_mfma_kernel():
+    """The split kernel's epilogue is dwordx4: a bias that is only 4-byte aligned makes the launcher fall back to the
+    fp32-MFMA kernel (dword epilogue) instead of faulting or refusing."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(4100, 128, device="cuda", generator=g)
+    w = torch.randn(256, 128, device="cuda", generator=g) * 0.1
+    bias = torch.randn(257, device="cuda", generator=g)[1:]         # data_ptr % 16 == 4
+    assert bias.data_ptr() % 16 != 0
+    got = fused_ops.linear_k128(x, w, bias, relu=True)
+    want = (x.double() @ w.double().t() + bias.double()).relu()
+    torch.testing.assert_close(got.double(), want, rtol=0, atol=2e-5)
+
+
 def test_linear_k128_fp32_mfma_variant_still_matches(tmp_path):
     """PCT_LIN_KERNEL=f32 selects the fp32-MFMA kernel (kept for A/B); the switch is read once per process."""
     import subprocess, sys, os
