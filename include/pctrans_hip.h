@@ -167,6 +167,15 @@ PCT_API int pct_groupnorm_flatten_f32(const float *x, const float *gamma, const 
 PCT_API int pct_linear_k128_f32(const float *x, long long ldx, const float *x_add, long long ld_add, long long add_period,
                                 const float *w, const float *bias, long long rows, int n, int act, float *y,
                                 long long ldy, void *stream);
+/* pct_linear_k128_multi_f32: nseg (1..4) Linear layers over the SAME rows in one launch, y[s] = (x [+ x_add]) . w[s]^T
+ *   + bias[s]: MSDeformAttn's value_proj(src), sampling_offsets(src + pos) and attention_weights(src + pos)
+ *   (ops/modules/ms_deform_attn.py:96-103) read the rows once instead of three times.  w, bias, n, use_add, y, ldy are
+ *   HOST arrays of nseg entries (device pointers / sizes); use_add[s] != 0 adds x_add to the rows of segment s;
+ *   n[s] % 32 == 0; w[s], bias[s], y[s] 16-byte aligned, ldy[s] % 4 == 0 (else PCT_ERR_ALIGNMENT). */
+PCT_API int pct_linear_k128_multi_f32(const float *x, long long ldx, const float *x_add, long long ld_add,
+                                      long long add_period, int nseg, const float *const *w, const float *const *bias,
+                                      const int *n, const int *use_add, float *const *y, const long long *ldy,
+                                      long long rows, void *stream);
 PCT_API int pct_linear_k128_add_layernorm_f32(const float *x, long long ldx, const float *w, const float *bias,
                                               const float *residual, long long ldr, const float *gamma,
                                               const float *beta, float eps, long long rows, float *out,

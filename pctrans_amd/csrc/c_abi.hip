@@ -17,6 +17,10 @@ int launch_linear_k128(const float *x, long long ldx, const float *x2, long long
                        long long rows, int n, int epi,
                        float *y, long long ldy, const float *residual, long long ldr, const float *gamma,
                        const float *beta, float eps, hipStream_t stream);
+int launch_linear_k128_split_multi(const float *x, long long ldx, const float *x2, long long ldx2, long long x2_period,
+                                   int nseg, const float *const *w, const float *const *bias, const int *n,
+                                   const int *use_add, float *const *y, const long long *ldy, long long rows,
+                                   hipStream_t stream);
 int launch_linear_ln_split(const float *x, long long ldx, const float *w, unsigned short *w_pieces, int K, const float *bias,
                            const float *residual, long long ldr, const float *gamma, const float *beta, float eps,
                            long long rows, float *out, long long ldo, hipStream_t stream);
@@ -255,6 +259,25 @@ int pct_linear_k128_f32(const float *x, long long ldx, const float *x_add, long 
   if ((((uintptr_t)x | (uintptr_t)w) & 15u) || (ldx & 3)) return PCT_ERR_ALIGNMENT;
   return pct::launch_linear_k128(x, ldx, x_add, ld_add, add_period, w, bias, rows, n, act, y, ldy, nullptr, 0, nullptr, nullptr, 0.f,
                                  static_cast<hipStream_t>(stream));
+}
+
+int pct_linear_k128_multi_f32(const float *x, long long ldx, const float *x_add, long long ld_add, long long add_period,
+                              int nseg, const float *const *w, const float *const *bias, const int *n, const int *use_add,
+                              float *const *y, const long long *ldy, long long rows, void *stream)
+{
+  if (rows < 0 || nseg < 1 || nseg > 4 || ldx < 128 || !w || !bias || !n || !use_add || !y || !ldy) return PCT_ERR_BAD_ARG;
+  if (x_add && (ld_add < 128 || (ld_add & 3) || ((uintptr_t)x_add & 15u))) return PCT_ERR_ALIGNMENT;
+  if (x_add && (add_period < 32 || add_period * ld_add * 4 > 0x7fffffffLL)) return PCT_ERR_BAD_ARG;
+  if (rows == 0) return PCT_OK;
+  if (!x) return PCT_ERR_BAD_ARG;
+  if (((uintptr_t)x & 15u) || (ldx & 3)) return PCT_ERR_ALIGNMENT;
+  for (int s = 0; s < nseg; ++s) {
+    if (!w[s] || !y[s] || n[s] <= 0 || ldy[s] < n[s]) return PCT_ERR_BAD_ARG;
+    if (n[s] % 32) return PCT_ERR_UNSUPPORTED;
+  }
+  const int rc = pct::launch_linear_k128_split_multi(x, ldx, x_add, ld_add, add_period, nseg, w, bias, n, use_add, y, ldy, rows,
+                                                     static_cast<hipStream_t>(stream));
+  return rc == -100 ? PCT_ERR_ALIGNMENT : (rc == -4 ? PCT_ERR_UNSUPPORTED : rc);
 }
 
 int pct_linear_k128_add_layernorm_f32(const float *x, long long ldx, const float *w, const float *bias,

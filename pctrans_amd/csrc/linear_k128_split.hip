@@ -75,11 +75,24 @@ __device__ __forceinline__ void spl_split(const float x, const float y, unsigned
   p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(spl_f32x2{sx, sy}, spl_bf16x2));
 }
 
+// Up to SPL_MAXSEG Linear layers that read the same rows in ONE launch (segment s: y_s = x_s W_s^T + b_s with
+// x_s = x or x + x2): their column slices are dealt to the same XCD like the slices of a single wide layer, so x is
+// read from HBM once for all of them (value_proj, sampling_offsets and attention_weights of MSDeformAttn all read src).
+constexpr int SPL_MAXSEG = 4;
+struct SplSegs {
+  const float *w[SPL_MAXSEG];
+  const float *bias[SPL_MAXSEG];
+  float *y[SPL_MAXSEG];
+  long long ldy[SPL_MAXSEG];
+  int n[SPL_MAXSEG];
+  int add_x2[SPL_MAXSEG];
+  int nseg;
+};
+
 template <int EPI, bool HAS_X2>
 __global__ __launch_bounds__(SPL_BLOCK, 2) void linear_k128_split_kernel(
     const float *__restrict__ X, const long long ldx, const float *__restrict__ X2, const long long ldx2,
-    const int x2_period, const float *__restrict__ W, const float *__restrict__ bias, const long long M, const int N,
-    float *__restrict__ Y, const long long ldy, const float *__restrict__ R, const long long ldr,
+    const int x2_period, const SplSegs segs, const long long M, const float *__restrict__ R, const long long ldr,
     const float *__restrict__ gamma, const float *__restrict__ beta, const float eps)
 {
   __shared__ __attribute__((aligned(16))) unsigned char abuf[2][SPL_IMAGE];
@@ -93,11 +106,38 @@ __global__ __launch_bounds__(SPL_BLOCK, 2) void linear_k128_split_kernel(
   // nslices column slices of one tile slot are given ids that differ by multiples of 8, so they run on the same XCD
   // at about the same time and the A tile they all read comes out of that XCD's L2 once (with a (tiles, slices) grid
   // the slices are whole passes apart and x is streamed from HBM once per 128 output columns).
-  const int nslices = (N + 127) / 128;
+  int nslices = 0;
+#pragma unroll
+  for (int g = 0; g < SPL_MAXSEG; ++g) nslices += g < segs.nseg ? (segs.n[g] + 127) / 128 : 0;
   const int nslots = gridDim.x / nslices;
   const int within = blockIdx.x >> 3;
-  const int slice = within % nslices;
   const int slot = (within / nslices) * 8 + (blockIdx.x & 7);
+  // my segment and my slice inside it (uniform)
+  int slice = within % nslices, seg = 0;
+#pragma unroll
+  for (int g = 0; g + 1 < SPL_MAXSEG; ++g) {
+    const int cnt = (segs.n[g] + 127) / 128;
+    if (g + 1 < segs.nseg && seg == g && slice >= cnt) {
+      slice -= cnt;
+      seg = g + 1;
+    }
+  }
+  const float *__restrict__ W = segs.w[0];
+  const float *__restrict__ bias = segs.bias[0];
+  float *__restrict__ Y = segs.y[0];
+  long long ldy = segs.ldy[0];
+  int N = segs.n[0];
+  bool add_x2 = segs.add_x2[0] != 0;
+#pragma unroll
+  for (int g = 1; g < SPL_MAXSEG; ++g)
+    if (seg == g) {
+      W = segs.w[g];
+      bias = segs.bias[g];
+      Y = segs.y[g];
+      ldy = segs.ldy[g];
+      N = segs.n[g];
+      add_x2 = segs.add_x2[g] != 0;
+    }
   const int col = slice * 128 + wave * 32 + r;               // my W row (A operand of the transposed product)
   const bool active = slice * 128 + wave * 32 < N;           // n % 32 == 0: wave-uniform
 
@@ -167,7 +207,9 @@ __global__ __launch_bounds__(SPL_BLOCK, 2) void linear_k128_split_kernel(
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       spl_f32x4 v = __builtin_bit_cast(spl_f32x4, g[q]);
-      if constexpr (HAS_X2) v += __builtin_bit_cast(spl_f32x4, g2[q]);
+      if constexpr (HAS_X2) {
+        if (add_x2) v += __builtin_bit_cast(spl_f32x4, g2[q]);
+      }
       unsigned a0, b0, c0, a1, b1, c1;
       spl_split(v[0], v[1], a0, b0, c0);
       spl_split(v[2], v[3], a1, b1, c1);
@@ -309,28 +351,22 @@ __global__ __launch_bounds__(SPL_BLOCK, 2) void linear_k128_split_kernel(
   }
 }
 
-// n must be a multiple of 32 (LayerNorm variant: exactly 128); x rows 16-byte aligned.  Returns -100 when the
-// operands do not allow the dwordx4 epilogue (caller uses the fp32-MFMA kernel).
-int launch_linear_k128_split(const float *x, long long ldx, const float *x2, long long ldx2, long long x2_period,
-                             const float *w, const float *bias, long long rows, int n, int epi, float *y, long long ldy,
-                             const float *residual, long long ldr, const float *gamma, const float *beta, float eps,
-                             hipStream_t stream)
+static int spl_launch(const float *x, long long ldx, const float *x2, long long ldx2, long long x2_period, const SplSegs &segs,
+                      long long rows, int epi, const float *residual, long long ldr, const float *gamma, const float *beta,
+                      float eps, hipStream_t stream)
 {
-  if (rows <= 0) return 0;
-  if ((((uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)gamma | (uintptr_t)beta) & 15u) || (ldy & 3) ||
-      (ldr & 3))
-    return -100;
   const long long ntiles = (rows + 31) / 32;
   static const int wgs = [] { const char *e = getenv("PCT_LIN_WGS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 2 ? 2 : v); }();
-  const int nslices = (n + 127) / 128;
+  int nslices = 0;
+  for (int g = 0; g < segs.nseg; ++g) nslices += (segs.n[g] + 127) / 128;
   // persistent: 2 workgroups per CU (VGPRs) when one slice covers n, else tile slots x slices (see the kernel)
   long long nslots = 256LL * wgs / (nslices < 8 ? nslices : 8) / 8 * 8;      // all resident at once
   if (nslots > (ntiles + 7) / 8 * 8) nslots = (ntiles + 7) / 8 * 8;
   if (nslots < 8) nslots = 8;
   const dim3 grid((unsigned)(nslots * nslices)), block(SPL_BLOCK);
 #define PCT_SPL(EPI_, X2_)                                                                                           \
-  hipLaunchKernelGGL((linear_k128_split_kernel<EPI_, X2_>), grid, block, 0, stream, x, ldx, x2, ldx2, (int)x2_period, w, \
-                     bias, rows, n, y, ldy, residual, ldr, gamma, beta, eps)
+  hipLaunchKernelGGL((linear_k128_split_kernel<EPI_, X2_>), grid, block, 0, stream, x, ldx, x2, ldx2, (int)x2_period, segs, \
+                     rows, residual, ldr, gamma, beta, eps)
   if (x2) {
     if (epi == SPL_EPI_BIAS) PCT_SPL(SPL_EPI_BIAS, true);
     else if (epi == SPL_EPI_BIAS_RELU) PCT_SPL(SPL_EPI_BIAS_RELU, true);
@@ -342,6 +378,54 @@ int launch_linear_k128_split(const float *x, long long ldx, const float *x2, lon
   }
 #undef PCT_SPL
   return (int)hipGetLastError();
+}
+
+// n must be a multiple of 32 (LayerNorm variant: exactly 128); x rows 16-byte aligned.  Returns -100 when the
+// operands do not allow the dwordx4 epilogue (caller uses the fp32-MFMA kernel).
+int launch_linear_k128_split(const float *x, long long ldx, const float *x2, long long ldx2, long long x2_period,
+                             const float *w, const float *bias, long long rows, int n, int epi, float *y, long long ldy,
+                             const float *residual, long long ldr, const float *gamma, const float *beta, float eps,
+                             hipStream_t stream)
+{
+  if (rows <= 0) return 0;
+  if ((((uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)gamma | (uintptr_t)beta) & 15u) || (ldy & 3) ||
+      (ldr & 3))
+    return -100;
+  SplSegs segs = {};
+  segs.w[0] = w;
+  segs.bias[0] = bias;
+  segs.y[0] = y;
+  segs.ldy[0] = ldy;
+  segs.n[0] = n;
+  segs.add_x2[0] = x2 ? 1 : 0;
+  segs.nseg = 1;
+  return spl_launch(x, ldx, x2, ldx2, x2_period, segs, rows, epi, residual, ldr, gamma, beta, eps, stream);
+}
+
+// several Linear layers over the same rows (bias epilogue only); every n[s] a multiple of 32, 1 <= nseg <= SPL_MAXSEG;
+// use_add[s] != 0: segment s multiplies x + x2.  Returns -100 when an operand is not 16-byte aligned.
+int launch_linear_k128_split_multi(const float *x, long long ldx, const float *x2, long long ldx2, long long x2_period,
+                                   int nseg, const float *const *w, const float *const *bias, const int *n,
+                                   const int *use_add, float *const *y, const long long *ldy, long long rows,
+                                   hipStream_t stream)
+{
+  if (rows <= 0) return 0;
+  if (nseg < 1 || nseg > SPL_MAXSEG) return -4;
+  SplSegs segs = {};
+  segs.nseg = nseg;
+  bool any_add = false;
+  for (int g = 0; g < nseg; ++g) {
+    if ((((uintptr_t)y[g] | (uintptr_t)bias[g] | (uintptr_t)w[g]) & 15u) || (ldy[g] & 3)) return -100;
+    segs.w[g] = w[g];
+    segs.bias[g] = bias[g];
+    segs.y[g] = y[g];
+    segs.ldy[g] = ldy[g];
+    segs.n[g] = n[g];
+    segs.add_x2[g] = (use_add[g] && x2) ? 1 : 0;
+    any_add |= segs.add_x2[g] != 0;
+  }
+  return spl_launch(x, ldx, any_add ? x2 : nullptr, ldx2, x2_period, segs, rows, SPL_EPI_BIAS, nullptr, 0, nullptr, nullptr,
+                    0.f, stream);
 }
 
 }  // namespace pct

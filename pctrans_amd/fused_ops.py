@@ -92,6 +92,44 @@ def linear_k128(x, weight, bias=None, relu=False, x_add=None):
     return out.view(*x.shape[:-1], n)
 
 
+def linear_k128_multi(x, layers, x_add=None):
+    """[lin(x + x_add if use_add else x) for (lin, use_add) in layers] in ONE launch of the K = 128 kernel: the rows are
+    read from HBM once for all layers (MSDeformAttn: value_proj(src), sampling_offsets(src + pos),
+    attention_weights(src + pos), ops/modules/ms_deform_attn.py:96-103).  Every layer must satisfy
+    linear_k128_supported; 1 <= len(layers) <= 4."""
+    import ctypes
+    x2 = _rows_2d(x)
+    rows = x2.shape[0]
+    a2, period = None, 0
+    if x_add is not None:
+        if x_add.shape[0] != 1 and x_add.stride(0) == 0:
+            x_add = x_add[:1]
+        a2 = _rows_2d(x_add)
+        period = a2.shape[0]
+    k = len(layers)
+    outs = [torch.empty((rows, lin.out_features), dtype=torch.float32, device=x.device) for lin, _ in layers]
+    vp, ll, ci = ctypes.c_void_p * k, ctypes.c_longlong * k, ctypes.c_int * k
+    w = vp(*[lin.weight.data_ptr() for lin, _ in layers])
+    b = vp(*[(lin.bias.data_ptr() if lin.bias is not None else None) for lin, _ in layers])
+    n = ci(*[lin.out_features for lin, _ in layers])
+    add = ci(*[1 if use else 0 for _, use in layers])
+    y = vp(*[o.data_ptr() for o in outs])
+    ldy = ll(*[o.shape[1] for o in outs])
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().pct_linear_k128_multi_f32(
+            x2.data_ptr(), x2.stride(0), a2.data_ptr() if a2 is not None else None,
+            a2.stride(0) if a2 is not None else 0, period, k, w, b, n, add, y, ldy, rows,
+            torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(rc, "linear_k128_multi")
+    return [o.view(*x.shape[:-1], o.shape[1]) for o in outs]
+
+
+def linear_k128_multi_supported(x, lins, x_add=None):
+    return (1 <= len(lins) <= 4 and all(linear_k128_supported(x, l.weight, l.bias) for l in lins)
+            and (x_add is None or _x_add_ok(x, x_add))
+            and all(l.weight.data_ptr() % 16 == 0 and (l.bias is None or l.bias.data_ptr() % 16 == 0) for l in lins))
+
+
 def linear(x, lin, relu=False, x_add=None):
     """[relu](lin(x [+ x_add])) for an nn.Linear: the K = 128 MFMA kernel when it applies, else the library GEMM (with
     the bias + ReLU in its epilogue)."""

@@ -116,15 +116,27 @@ class MSDeformAttn(nn.Module):
                 _CHECKED_SHAPES.clear()
             _CHECKED_SHAPES.add(key)
 
-        value = fused_ops.linear(input_flatten, self.value_proj)     # K = 128 MFMA kernel when forward-only fp32
+        # encoder self-attention: the three input projections read the same rows (query is input_flatten): one launch
+        merged = None
+        if (query is input_flatten and input_padding_mask is None and reference_points.shape[-1] == 2
+                and self.d_model // self.n_heads == 16 and self.n_points in (4, 8) and self.n_heads <= 16
+                and fused_ops.linear_k128_multi_supported(
+                    query, (self.value_proj, self.sampling_offsets, self.attention_weights), _query_pos)):
+            merged = fused_ops.linear_k128_multi(
+                query, ((self.value_proj, False), (self.sampling_offsets, True), (self.attention_weights, True)),
+                x_add=_query_pos)
+        value = merged[0] if merged is not None else \
+            fused_ops.linear(input_flatten, self.value_proj)         # K = 128 MFMA kernel when forward-only fp32
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
         if self._can_fuse(value, query, reference_points):
             # one launch: softmax + location math + sampling (no sampling_locations tensor, no softmax output)
-            offsets = fused_ops.linear(query, self.sampling_offsets, x_add=_query_pos).view(
+            offsets = (merged[1] if merged is not None else
+                       fused_ops.linear(query, self.sampling_offsets, x_add=_query_pos)).view(
                 N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
-            logits = fused_ops.linear(query, self.attention_weights, x_add=_query_pos).view(
+            logits = (merged[2] if merged is not None else
+                      fused_ops.linear(query, self.attention_weights, x_add=_query_pos)).view(
                 N, Len_q, self.n_heads, self.n_levels * self.n_points)
             output = MSDA.ms_deform_attn_fused_forward(
                 value.contiguous(), input_spatial_shapes, input_level_start_index, reference_points,

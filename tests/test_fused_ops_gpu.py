@@ -170,6 +170,26 @@ def test_linear_k128_split_products_keep_fp32_accuracy_over_the_exponent_range()
     assert err <= 2.0 * lib + 1e-8, (err, lib)
 
 
+@pytest.mark.parametrize("S,shared", [(5376, True), (4099, False)])
+def test_linear_k128_multi_equals_the_separate_launches(S, shared):
+    """value_proj(src), sampling_offsets(src + pos), attention_weights(src + pos) in one launch (the rows are read once):
+    same kernel arithmetic per output column, so the results are bit-identical to three launches."""
+    torch.manual_seed(S)
+    x = torch.randn(3, S, 128, device="cuda")
+    pos = torch.randn(1 if shared else 3, S, 128, device="cuda")
+    lv, lo, la = (torch.nn.Linear(128, n).cuda() for n in (128, 256, 128))
+    with torch.no_grad():
+        assert fused_ops.linear_k128_multi_supported(x, (lv, lo, la), pos)
+        got = fused_ops.linear_k128_multi(x, ((lv, False), (lo, True), (la, True)), x_add=pos)
+        want = [fused_ops.linear_k128(x, lv.weight, lv.bias),
+                fused_ops.linear_k128(x, lo.weight, lo.bias, x_add=pos),
+                fused_ops.linear_k128(x, la.weight, la.bias, x_add=pos)]
+        ref64 = (x.double() + pos.double()) @ lo.weight.double().t() + lo.bias.double()
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and torch.equal(g, w)
+    torch.testing.assert_close(got[1].double(), ref64, rtol=0, atol=3e-5)
+
+
 def test_linear_k128_unaligned_bias_takes_the_fp32_mfma_kernel():
     """The split kernel's epilogue is dwordx4: a bias that is only 4-byte aligned makes the launcher fall back to the
     fp32-MFMA kernel (dword epilogue) instead of faulting or refusing."""
