@@ -87,10 +87,17 @@ def cpu_baseline(args, levels_hw):
         orc.forward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"])
         reps += 1
         el = time.perf_counter() - t0
-        if el >= args.cpu_seconds or reps >= 200:
+        if el >= args.cpu_seconds or reps >= 20000:
             break
     alg_bytes = S * (2 * 128 * 4 + 3 * 8 * len(levels_hw) * 4 * 4)
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
     return {"value": reps / el, "unit": "MSDeformAttn-forward image-layers/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model,
             "sample": "oracle/msda_oracle.c (C + OpenMP, %d threads) forward, 1 image x %d reps, levels %s, S=%d, "
                       "M=8 D=16 P=4 fp32, model-like locations" % (threads, reps, list(levels_hw), S),
             "ms_per_image_layer": 1e3 * el / reps, "algorithmic_GBps": alg_bytes * reps / el / 1e9}
