@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
     ap.add_argument("--image", type=int, default=512)
     ap.add_argument("--queries", type=int, default=100)
     ap.add_argument("--levels", type=int, default=4, choices=[3, 4],
