@@ -94,12 +94,8 @@ __global__ __launch_bounds__(WIN_BLOCK, 2) void msda_backward_win_kernel(
   // items: first round static, then from the XCD's self-resetting counter (msda_win_common.hpp: win_queue_slot)
   int item = xcd * chunk + slot0;
   while (item < item_end) {
-    unsigned fetched = (unsigned)(item - xcd * chunk + nslots);     // static stride when there is no queue
-    if (queue && tid == 0) {
-      const unsigned r = atomicAdd(queue + xcd, 1u);
-      if (r + 1u >= (unsigned)(item_end - xcd * chunk)) atomicExch(queue + xcd, 0u);
-      fetched = (unsigned)nslots + r;
-    }
+    unsigned rfetch = 0u;                                            // looked at right before barrier (1)
+    if (queue && tid == 0) rfetch = atomicAdd(queue + xcd, 1u);
     const int m = item % M;
     const int bt = item / M;
     const int t = bt % T_img;
@@ -186,7 +182,14 @@ __global__ __launch_bounds__(WIN_BLOCK, 2) void msda_backward_win_kernel(
         }
       }
     }
-    if (tid == 0) next_idx[0] = fetched;
+    if (tid == 0) {
+      unsigned fetched = (unsigned)(item - xcd * chunk + nslots);   // static stride when there is no queue
+      if (queue) {
+        if (rfetch + 1u >= (unsigned)(item_end - xcd * chunk)) atomicExch(queue + xcd, 0u);
+        fetched = (unsigned)nslots + rfetch;
+      }
+      next_idx[0] = fetched;
+    }
     __syncthreads();                                               // (1) boxes visible; previous item's flush done
     int next_item;
     {

@@ -237,12 +237,9 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
     stamp(0);
     __syncthreads();                                               // (A) boxes visible; pool free
     stamp(1);
-    unsigned fetched = (unsigned)(item - xcd * chunk + nslots);     // static stride when there is no queue
-    if (queue && tid == 0) {
-      const unsigned r = atomicAdd(queue + xcd, 1u);
-      if (r + 1u >= (unsigned)(item_end - xcd * chunk)) atomicExch(queue + xcd, 0u);
-      fetched = (unsigned)nslots + r;
-    }
+    // (the counter's answer is first looked at right before barrier (2): the round trip hides behind the staging)
+    unsigned rfetch = 0u;
+    if (queue && tid == 0) rfetch = atomicAdd(queue + xcd, 1u);
 
     // ---- windows (identical in every lane; kept in SGPRs) -------------------------------------------------------
     int wx0[L], wy0[L], wwid[L], wbase[L], wsize[L], in_lds[L];
@@ -324,7 +321,14 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
       }
     };
     issue_points((okmask & 1u) ? q0 : 0);
-    if (tid == 0) next_idx[0] = fetched;
+    if (tid == 0) {
+      unsigned fetched = (unsigned)(item - xcd * chunk + nslots);   // static stride when there is no queue
+      if (queue) {
+        if (rfetch + 1u >= (unsigned)(item_end - xcd * chunk)) atomicExch(queue + xcd, 0u);
+        fetched = (unsigned)nslots + rfetch;
+      }
+      next_idx[0] = fetched;
+    }
     __syncthreads();                                               // (2) windows staged; next item known
     stamp(4);
 
