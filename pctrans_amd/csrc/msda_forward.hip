@@ -200,7 +200,8 @@ int launch_msda_forward_dpp(const void *, const int64_t *, const int64_t *, cons
 
 // Kernel choice for PCTrans' geometry.  Default "auto": the windowed-LDS kernel when the queries are the pyramid's
 // own pixels (Lq == S: neighbouring queries sample neighbouring texels, the case it is built for) and the problem fills
-// its persistent grid, else the quad-owner kernel.  PCT_MSDA_KERNEL = auto | win | dpp | generic (development A/B).
+// its persistent grid (except where it was measured slower, see below), else the quad-owner kernel.
+// PCT_MSDA_KERNEL = auto | win | dpp | generic (development A/B).
 int msda_kernel_choice()
 {
   static const int v = [] {
@@ -223,7 +224,11 @@ int launch_msda_forward_special(const void *value, const int64_t *shapes, const 
   const int choice = msda_kernel_choice();
   if (choice == 2) return -100;
   int rc = -100;
-  if (choice == 1 || (choice == 0 && Lq == S))
+  // 16-bit values with 8 points per level (SURVEY config 5): the windowed variant (2 lanes per head-pixel, 4 points per
+  // lane and level, 20-40 spilled VGPRs) loses to the quad-owner kernel (P3, N = 1: 0.49 vs 0.34 ms) -- measured, so
+  // "auto" skips it there; fp32 with 8 points and 16-bit with 4 points stay on the windowed kernel (faster)
+  const bool win_loses = sizeof(typename Traits<T>::store_t) == 2 && P == 8;
+  if (choice == 1 || (choice == 0 && Lq == S && !win_loses))
     rc = launch_msda_forward_win<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream, ref,
                                     ref_batch_stride);
   if (rc == -100)
