@@ -17,6 +17,7 @@ int launch_linear_k128(const float *x, long long ldx, const float *x2, long long
                        long long rows, int n, int epi,
                        float *y, long long ldy, const float *residual, long long ldr, const float *gamma,
                        const float *beta, float eps, hipStream_t stream);
+void set_msda_kernel_choice(int v);
 int launch_linear_k128_split_multi(const float *x, long long ldx, const float *x2, long long ldx2, long long x2_period,
                                    int nseg, const float *const *w, const float *const *bias, const int *n,
                                    const int *use_add, float *const *y, const long long *ldy, long long rows,
@@ -260,6 +261,8 @@ int pct_linear_k128_f32(const float *x, long long ldx, const float *x_add, long 
   return pct::launch_linear_k128(x, ldx, x_add, ld_add, add_period, w, bias, rows, n, act, y, ldy, nullptr, 0, nullptr, nullptr, 0.f,
                                  static_cast<hipStream_t>(stream));
 }
+
+void pct_msda_set_kernel_choice(int choice) { pct::set_msda_kernel_choice(choice); }
 
 int pct_linear_k128_multi_f32(const float *x, long long ldx, const float *x_add, long long ld_add, long long add_period,
                               int nseg, const float *const *w, const float *const *bias, const int *n, const int *use_add,

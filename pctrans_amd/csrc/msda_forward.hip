@@ -202,8 +202,12 @@ int launch_msda_forward_dpp(const void *, const int64_t *, const int64_t *, cons
 // own pixels (Lq == S: neighbouring queries sample neighbouring texels, the case it is built for) and the problem fills
 // its persistent grid (except where it was measured slower, see below), else the quad-owner kernel.
 // PCT_MSDA_KERNEL = auto | win | dpp | generic (development A/B).
+static int g_kernel_override = -1;                 // pct_msda_set_kernel_choice (diagnostic): -1 = follow the environment
+void set_msda_kernel_choice(int v) { g_kernel_override = (v >= 0 && v <= 3) ? v : -1; }
+
 int msda_kernel_choice()
 {
+  if (g_kernel_override >= 0) return g_kernel_override;
   static const int v = [] {
     const char *e = getenv("PCT_MSDA_KERNEL");
     if (!e) return 0;
@@ -228,7 +232,11 @@ int launch_msda_forward_special(const void *value, const int64_t *shapes, const 
   // lane and level, 20-40 spilled VGPRs) loses to the quad-owner kernel (P3, N = 1: 0.49 vs 0.34 ms) -- measured, so
   // "auto" skips it there; fp32 with 8 points and 16-bit with 4 points stay on the windowed kernel (faster)
   const bool win_loses = sizeof(typename Traits<T>::store_t) == 2 && P == 8;
-  if (choice == 1 || (choice == 0 && Lq == S && !win_loses))
+  // ... and a persistent grid of 768 workgroups needs about three work items each to beat the quad-owner kernel
+  // (P2: N = 1 0.046 vs 0.040 ms, N = 2 equal, N = 4 0.089 vs 0.113 ms; P4, N = 1: 0.024 vs 0.014 ms)
+  const long long per_item = P == 8 ? 128 : (sizeof(typename Traits<T>::store_t) == 2 ? 512 : 256);   // queries per item
+  const bool win_small = (long long)N * ((Lq + per_item - 1) / per_item) * M < 3 * 768;
+  if (choice == 1 || (choice == 0 && Lq == S && !win_loses && !win_small))
     rc = launch_msda_forward_win<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream, ref,
                                     ref_batch_stride);
   if (rc == -100)
