@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- MSDeformAttn pixel decoder + PCTrans transformer decoder forward throughput on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank/GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Started bare (`python bench.py --gpus N`, no WORLD_SIZE in the environment) this
+process never touches a GPU: it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child
+and exits with its code; started by torch.distributed.run itself (the driver's form) it is one of the N ranks.
 
 One "step" = one forward of MaskFormerHead (pixel decoder with 6 MSDeformAttn encoder layers + 9-layer position-
 guided masked-attention decoder + per-query dynamic mask head) over one batch of synthetic ResNet-50-shaped feature
@@ -123,26 +127,49 @@ def traffic_from_profile(args):
     return None
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` (the
+    reference's launch, README.md:30-33, in its current spelling) and return its exit code.  Nothing in this process
+    has touched the GPU (device_count() does not initialise it), and it never replaces itself with another program."""
+    import socket
+    import subprocess
+    share = os.environ.get("PCT_BENCH_SHARE_GPU") == "1"
+    ndev = torch.cuda.device_count()
+    if not share and args.gpus > ndev:
+        print("bench.py: --gpus %d but %d GPU(s) visible (PCT_BENCH_SHARE_GPU=1 rehearses several ranks on one card "
+              "over gloo)" % (args.gpus, ndev), file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
-    if world > 1:
-        assert world == args.gpus, "--gpus must equal WORLD_SIZE"
     # PCT_BENCH_SHARE_GPU=1 (rehearsal only): several ranks on one card over gloo, to exercise the multi-rank code path
-    # on a 1-GPU box; the judged runs use one GPU per rank over RCCL.
+    # on a 1-GPU box; the judged runs use one GPU per rank over RCCL ('nccl' == RCCL on ROCm).
     share = os.environ.get("PCT_BENCH_SHARE_GPU") == "1"
-    if share:
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        if share:
-            dist.init_process_group("gloo", init_method="env://")
-        else:
-            dist.init_process_group("nccl", init_method="env://", device_id=device)   # nccl == RCCL on ROCm
+    from pctrans_amd.parallel import init_devices
+    device, rank, local_rank, world = init_devices(distributed=world > 1, backend="nccl", manual_seed=0,
+                                                   share_gpu=share)
+    torch.cuda.set_device(device)
 
     from pctrans_amd import MultiScaleDeformableAttention as MSDA
     from pctrans_amd import _lib
@@ -197,6 +224,8 @@ def main():
             "value": world * args.batch * args.steps / elapsed,
             "unit": "samples/s",
             "n_gpus": world,
+            "world_size_observed": dist.get_world_size() if world > 1 else 1,
+            "backend": dist.get_backend() if world > 1 else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,

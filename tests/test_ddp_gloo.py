@@ -1,5 +1,6 @@
 """CPU, world_size 2, gloo: the multi-GPU launch semantics of the path -- one process per device,
-images sharded across ranks, DDP(find_unused_parameters=True) as the reference's make_parallel does (connectomics/model/build.py:74-102), env:// rendezvous as connectomics/utils/system.py:58-70.
+images sharded across ranks, through pctrans_amd.parallel: init_devices (env:// rendezvous, connectomics/utils/system.py:58-70)
+and make_parallel (SyncBatchNorm conversion + DDP(find_unused_parameters=True), connectomics/model/build.py:74-102).
 Forward needs no collective; backward all-reduces gradients: after one step both ranks must hold identical gradients
 equal to the mean of the per-shard gradients computed without DDP."""
 import os
@@ -43,16 +44,23 @@ def _worker(rank, world, port, out_dir):
     torch.set_num_threads(2)
     from pctrans_amd.pixel_decoder.ops.modules import ms_deform_attn as msda_mod
     msda_mod.allow_cpu_reference(True)
-    dist.init_process_group("gloo", init_method="env://")
+    from pctrans_amd import parallel
+    device, r, lr, w = parallel.init_devices(backend="gloo")
+    assert (device.type, r, lr, w) == ("cpu", rank, rank, world) and dist.get_backend() == "gloo"
     head, shapes = _build()
-    head = head.eval()      # SyncBatchNorm conversion (build.py:80-81) is GPU-only in torch; BN in eval = same math
-    ddp = torch.nn.parallel.DistributedDataParallel(head, find_unused_parameters=True)
+    ddp = parallel.make_parallel(head, device, parallel="DDP", norm_mode="sync_bn")
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel) and ddp.find_unused_parameters
+    # the shipped configs' BatchNorms (NORM / SEMANTIC_NORM: SyncBN) become SyncBatchNorm as build.py:80-81 does -- on
+    # GPU ranks; torch's DDP refuses SyncBatchNorm on CPU modules, so this rehearsal keeps BatchNorm (same math in eval)
+    nbn = sum(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in head.modules())
+    assert nbn >= 2 and sum(isinstance(m, torch.nn.SyncBatchNorm) for m in parallel.convert_norms(head).modules()) == nbn
+    ddp.eval()
+    head = ddp.module
     pred, _ = ddp(_shard(rank, shapes))
     _loss(pred).backward()
     grads = {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None}
     torch.save(grads, os.path.join(out_dir, "g%d.pt" % rank))
-    dist.barrier()
-    dist.destroy_process_group()
+    parallel.shutdown()
 
 
 @pytest.mark.timeout(600)
@@ -81,3 +89,30 @@ def test_ddp_two_ranks_gloo(tmp_path):
             torch.testing.assert_close(g0[k], want[k] / world, rtol=1e-4, atol=1e-6, msg=k)
     finally:
         msda_mod.allow_cpu_reference(prev)
+
+
+def _run_bench(extra_env, *argv):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=env, capture_output=True,
+                          text=True, timeout=600)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-box behaviour")
+@pytest.mark.timeout(900)
+def test_bench_gpus_n_never_reports_one_rank_as_n():
+    """`python bench.py --gpus 2` from a bare shell must either run 2 ranks or fail: never rc 0 with n_gpus 1."""
+    r = _run_bench({}, "--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0 and '"n_gpus"' not in r.stdout, (r.returncode, r.stdout[-300:])
+    assert "GPU(s) visible" in r.stderr
+    # with the rehearsal switch the parent does start torch.distributed.run; on a box without a GPU both ranks fail
+    # their "needs an MI355X" check and the parent reports the children's failure
+    r = _run_bench({"PCT_BENCH_SHARE_GPU": "1"}, "--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0 and '"n_gpus"' not in r.stdout, (r.returncode, r.stdout[-300:])
+    assert "needs an MI355X" in r.stderr
+    # a launcher/--gpus mismatch is an error too
+    r = _run_bench({"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2")
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
