@@ -167,10 +167,17 @@ PCT_API int pct_groupnorm_flatten_f32(const float *x, const float *gamma, const 
 PCT_API int pct_linear_k128_f32(const float *x, long long ldx, const float *x_add, long long ld_add, long long add_period,
                                 const float *w, const float *bias, long long rows, int n, int act, float *y,
                                 long long ldy, void *stream);
-/* Diagnostic: forward kernel selection for this process, overriding PCT_MSDA_KERNEL: 0 = auto (windowed-LDS kernel when
- * Lq == S and the problem gives its persistent grid about three items per workgroup, else quad-owner), 1 = windowed,
- * 2 = generic, 3 = quad-owner, anything else = follow the environment again.  Results do not depend on the choice. */
+/* Diagnostics (tests and A/B measurements; not part of the reference's interface).
+ * pct_msda_set_kernel_choice: forward kernel selection for this process, overriding PCT_MSDA_KERNEL: 0 = auto (fp32,
+ *   Lq == S, 4 points and at least two work items per CU: pyramid-column kernel; else the windowed-LDS kernel when
+ *   Lq == S and the problem gives its persistent grid about three items per workgroup; else quad-owner), 1 = windowed,
+ *   2 = generic, 3 = quad-owner, 4 = pyramid-column, anything else = follow the environment again.  A forced kernel
+ *   that does not cover the call's geometry falls through as in auto.  Results do not depend on the choice.
+ * pct_msda_last_kernel: which forward kernel the most recent pct_ms_deform_attn_*forward* call of this process
+ *   launched: 1 = windowed, 2 = generic, 3 = quad-owner, 4 = pyramid-column, 0 = none yet.  Both are process-wide
+ *   atomics; concurrent callers see each other's values. */
 PCT_API void pct_msda_set_kernel_choice(int choice);
+PCT_API int pct_msda_last_kernel(void);
 
 /* pct_linear_k128_multi_f32: nseg (1..4) Linear layers over the SAME rows in one launch, y[s] = (x [+ x_add]) . w[s]^T
  *   + bias[s]: MSDeformAttn's value_proj(src), sampling_offsets(src + pos) and attention_weights(src + pos)

@@ -17,6 +17,8 @@
 //   * logical block order is remapped so that each XCD's L2 serves one contiguous range of queries.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "msda_common.hpp"
 
 namespace pct {
@@ -198,22 +200,30 @@ template <typename T>
 int launch_msda_forward_dpp(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
                             int, int, int, int, void *, hipStream_t, const float *, long long);   // msda_forward_dpp.hip
 
+int launch_msda_forward_col(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
+                            int, int, int, int, void *, hipStream_t, const float *, long long);   // msda_forward_col.hip
+
 // Kernel choice for PCTrans' geometry.  Default "auto": the windowed-LDS kernel when the queries are the pyramid's
 // own pixels (Lq == S: neighbouring queries sample neighbouring texels, the case it is built for) and the problem fills
 // its persistent grid (except where it was measured slower, see below), else the quad-owner kernel.
-// PCT_MSDA_KERNEL = auto | win | dpp | generic (development A/B).
-static int g_kernel_override = -1;                 // pct_msda_set_kernel_choice (diagnostic): -1 = follow the environment
-void set_msda_kernel_choice(int v) { g_kernel_override = (v >= 0 && v <= 3) ? v : -1; }
+// PCT_MSDA_KERNEL = auto | win | dpp | generic | col (development A/B).
+static std::atomic<int> g_kernel_override{-1};     // pct_msda_set_kernel_choice (diagnostic): -1 = follow the environment
+static std::atomic<int> g_last_kernel{0};          // pct_msda_last_kernel (diagnostic): what the last forward call launched
+void set_msda_kernel_choice(int v) { g_kernel_override.store((v >= 0 && v <= 4) ? v : -1, std::memory_order_relaxed); }
+int msda_last_kernel() { return g_last_kernel.load(std::memory_order_relaxed); }
+void note_msda_kernel(int k) { g_last_kernel.store(k, std::memory_order_relaxed); }
 
 int msda_kernel_choice()
 {
-  if (g_kernel_override >= 0) return g_kernel_override;
+  const int ov = g_kernel_override.load(std::memory_order_relaxed);
+  if (ov >= 0) return ov;
   static const int v = [] {
     const char *e = getenv("PCT_MSDA_KERNEL");
     if (!e) return 0;
     if (e[0] == 'w') return 1;
     if (e[0] == 'd') return 3;
     if (e[0] == 'g') return 2;
+    if (e[0] == 'c') return 4;
     return 0;
   }();
   return v;
@@ -236,12 +246,25 @@ int launch_msda_forward_special(const void *value, const int64_t *shapes, const 
   // (P2: N = 1 0.046 vs 0.040 ms, N = 2 equal, N = 4 0.089 vs 0.113 ms; P4, N = 1: 0.024 vs 0.014 ms)
   const long long per_item = P == 8 ? 128 : (sizeof(typename Traits<T>::store_t) == 2 ? 512 : 256);   // queries per item
   const bool win_small = (long long)N * ((Lq + per_item - 1) / per_item) * M < 3 * 768;
-  if (choice == 1 || (choice == 0 && Lq == S && !win_loses && !win_small))
+  // the pyramid-column kernel (fp32, 4 points): one 1024-thread workgroup per CU, items of <= 1024 queries -- it needs
+  // about two items per workgroup before it beats the windowed kernel
+  if constexpr (sizeof(typename Traits<T>::store_t) == 4) {
+    const bool col_big = (long long)N * S * M >= 2LL * 256 * 900;
+    if (choice == 4 || (choice == 0 && Lq == S && P == 4 && col_big)) {
+      rc = launch_msda_forward_col(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream, ref, ref_batch_stride);
+      if (rc != -100) note_msda_kernel(4);
+    }
+  }
+  if (rc == -100 && (choice == 1 || (choice == 0 && Lq == S && !win_loses && !win_small))) {
     rc = launch_msda_forward_win<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream, ref,
                                     ref_batch_stride);
-  if (rc == -100)
+    if (rc != -100) note_msda_kernel(1);
+  }
+  if (rc == -100) {
     rc = launch_msda_forward_dpp<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream, ref,
                                     ref_batch_stride);
+    if (rc != -100) note_msda_kernel(3);
+  }
   return rc;
 }
 template int launch_msda_forward_special<float>(const void *, const int64_t *, const int64_t *, const void *,
@@ -261,6 +284,7 @@ int launch_msda_forward(const void *value, const int64_t *shapes, const int64_t 
                                                   nullptr, 0);
     if (rc != -100) return rc;
   }
+  note_msda_kernel(2);
   constexpr int VECW = 16 / (int)sizeof(ST);                    // channels in one 16-byte lane load
   const bool aligned16 = (((uintptr_t)value | (uintptr_t)out) & 15u) == 0 &&
                          (((uintptr_t)loc | (uintptr_t)attn) & 15u) == 0;
