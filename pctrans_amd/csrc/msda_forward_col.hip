@@ -50,14 +50,92 @@ __device__ __forceinline__ float uni(const float v)
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
-template <int L, bool FUSED, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void msda_forward_col_kernel(
+// ---- quad-cooperative record access ------------------------------------------------------------------------------------
+// A lane's records (128 B of sampling locations, 64 B of weights, 64 B of output per (query, head)) are 512 B - 1 KB apart
+// from its neighbours': loaded lane by lane, every 16-byte access of a wave instruction touches a different 128-byte line
+// and the texture-addresser serialises them (64 tag look-ups per instruction; measured: 16 K of the 77 K cycles an
+// item took, and everything behind it in the queue waits).  So the 4 lanes of a quad fetch 64 CONSECUTIVE bytes of ONE
+// record per instruction (16 look-ups), taking the quad's four records in turn, and the 4 x 4 block of 16-byte pieces is
+// transposed in registers: instruction s gives lane i piece (s - i) % 4 of record s; the lane rotates its four registers
+// by its own index (two layers of v_cndmask) and a quad_perm rotation by k delivers piece k of its own record.
+template <int K>
+__device__ __forceinline__ col_f32x4 quad_rot(const col_f32x4 v)      // lane c receives lane (c - K) % 4's value
+{
+  constexpr int ctrl = ((0 - K) & 3) | (((1 - K) & 3) << 2) | (((2 - K) & 3) << 4) | (((3 - K) & 3) << 6);
+  if constexpr (K == 0) return v;
+  return col_f32x4{dpp_f<ctrl>(v[0]), dpp_f<ctrl>(v[1]), dpp_f<ctrl>(v[2]), dpp_f<ctrl>(v[3])};
+}
+// x[k] <- x[(a + k) % 4] with the per-lane amount a = a0 + 2 * a1
+__device__ __forceinline__ void rot_regs(col_f32x4 (&x)[4], const bool a0, const bool a1)
+{
+  col_f32x4 t[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[k][e] = a0 ? x[(k + 1) & 3][e] : x[k][e];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[k][e] = a1 ? t[(k + 2) & 3][e] : t[k][e];
+}
+// in: x[s] = what this lane loaded for record s of its quad (piece (s - i) % 4); out: x[k] = piece k of its own record
+__device__ __forceinline__ void quad_transpose_in(col_f32x4 (&x)[4], const bool i0, const bool i1)
+{
+  rot_regs(x, i0, i1);
+  x[1] = quad_rot<1>(x[1]);
+  x[2] = quad_rot<2>(x[2]);
+  x[3] = quad_rot<3>(x[3]);
+}
+
+__device__ __forceinline__ double uni_d(const double v)
+{
+  // (explicit v_readfirstlane: the builtin is folded away on a value the compiler already knows to be uniform, and the
+  // vector copy then stays alive across the item loop -- five of these were spilled)
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned ul = (unsigned)u, uh = (unsigned)(u >> 32);
+  unsigned lo, hi;
+  asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(lo), "=s"(hi) : "v"(ul), "v"(uh));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// a uniform (x, y) pair in an aligned scalar register pair: a packed FMA takes it as an operand directly (built in vector
+// registers instead, the per-level constant pairs were hoisted out of the item loop and spilled)
+__device__ __forceinline__ col_f32x2 uni_pair(const float a, const float b)
+{
+  const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+  unsigned lo, hi;
+  asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(lo), "=s"(hi) : "v"(ua), "v"(ub));
+  return __builtin_bit_cast(col_f32x2, ((unsigned long long)hi << 32) | lo);
+}
+
+// floor(n / d) for uniform 0 <= n < 2^31 given inv = 1.0 / d: (n + 0.5) / d is at least 0.5 / d away from an integer and
+// the double product is off by less than 2^-20 of that margin.  An integer division by a run-time divisor costs ~35
+// dependent instructions here (no hardware divide); the item decode had twenty of them per item.
+__device__ __forceinline__ int udiv_by(const int n, const double inv)
+{
+  return __builtin_amdgcn_readfirstlane((int)(((double)n + 0.5) * inv));
+}
+
+template <int L, bool FUSED, int BLOCK, bool STAMP = false>
+__global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) void msda_forward_col_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const float *__restrict__ loc, const float *__restrict__ attn, const int N, const int S, const int M,
     const int pool_px, float *__restrict__ out, const float *__restrict__ ref, const long long ref_batch_stride,
-    unsigned *__restrict__ queue)
+    unsigned *__restrict__ queue, unsigned long long *__restrict__ stamps = nullptr)
 {
   constexpr int P = 4, D = 16, PXB = 64, NW = BLOCK / 64;
+  // diagnostic build only (STAMP): per-phase cycle sums of wave 0, written to a buffer nothing else reads
+  unsigned long long t_prev = 0, t_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int phase) {
+    if constexpr (STAMP) {
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (phase >= 0) t_sum[phase] += t - t_prev;
+      t_prev = t;
+    }
+  };
   static_assert(L >= 1 && L <= 5 && NW <= 16, "unsupported geometry");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -65,12 +143,14 @@ __global__ __launch_bounds__(BLOCK) void msda_forward_col_kernel(
   unsigned *bb = reinterpret_cast<unsigned *>(smem_raw + (size_t)pool_px * PXB);   // [NW][L][2] per-wave boxes
   unsigned *next_idx = bb + NW * L * 2;                                        // the workgroup's next item
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
   const int MD = M * D;
 
   // ---- level geometry (uniform) -------------------------------------------------------------------------------------
   int Hs[L], Ws[L], St[L];
-  float fH[L], fW[L], invW[L], invH[L];
+  float fH[L], fW[L];
+  col_f32x2 fWH[L], invWH[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     Hs[l] = (int)shapes[2 * l];
@@ -78,8 +158,8 @@ __global__ __launch_bounds__(BLOCK) void msda_forward_col_kernel(
     St[l] = (int)starts[l];
     fH[l] = uni((float)Hs[l]);
     fW[l] = uni((float)Ws[l]);
-    invW[l] = uni(1.0f / (float)Ws[l]);                                       // FUSED: offset / W as offset * (1 / W)
-    invH[l] = uni(1.0f / (float)Hs[l]);
+    fWH[l] = uni_pair((float)Ws[l], (float)Hs[l]);
+    invWH[l] = uni_pair(1.0f / (float)Ws[l], 1.0f / (float)Hs[l]);           // FUSED: offset / (W, H) as offset * (1 / W, 1 / H)
   }
 
   // ---- column grid (uniform; every workgroup derives the same one): CX x CY cells such that no column holds more than
@@ -92,7 +172,7 @@ __global__ __launch_bounds__(BLOCK) void msda_forward_col_kernel(
       if (Hs[l] * Ws[l] > Hf * Wf) { Hf = Hs[l]; Wf = Ws[l]; }
     const float area = (float)BLOCK * (float)(Hf * Wf) / (float)S;           // finest-level pixels per full column
     const int side = (int)sqrtf(area);
-    const int nxt = min(Wf, max(8, (side + 7) & ~7));
+    const int nxt = min(Wf, max(8, (side + 4) & ~7));
     CX = (Wf + nxt - 1) / nxt;
     const int nx0 = (Wf + CX - 1) / CX;
     const int nyt = max(1, (int)(area / (float)nx0));
@@ -114,9 +194,19 @@ __global__ __launch_bounds__(BLOCK) void msda_forward_col_kernel(
   }
   const int ncol = CX * CY;
   const int items = N * ncol * M;
+  const double inv_M = uni_d(1.0 / (double)M), inv_ncol = uni_d(1.0 / (double)ncol), inv_CX = uni_d(1.0 / (double)CX);
+  const double inv_2CX = uni_d(0.5 / (double)CX), inv_2CY = uni_d(0.5 / (double)CY);
+  auto col_lo_f = [&](const int c, const int W, const int C, const double inv_2C) {   // == col_lo(c, W, C)
+    return udiv_by(2 * c * W + C - 1, inv_2C);
+  };
 
   // pixels 0 and 1 of the pool are zeros: gated-out samples read them (weight 0 times a guaranteed-finite value)
   if (tid < 8) reinterpret_cast<col_f32x4 *>(pool)[tid] = col_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // this lane's place in its quad (quad-cooperative record access, above)
+  int qi = lane & 3;
+  const bool qi0 = qi & 1, qi1 = qi & 2;
+  const bool qn1 = ((4 - qi) & 3) & 2;                                         // bit 1 of (-qi) % 4 (bit 0 is qi0)
 
   // per-lane rotation of the four 16-byte pieces of a head-pixel (see the header)
   const unsigned rho = (unsigned)(lane >> 3) & 3u;
@@ -124,67 +214,161 @@ __global__ __launch_bounds__(BLOCK) void msda_forward_col_kernel(
 #pragma unroll
   for (int j = 0; j < 4; ++j) rot[j] = ((j + rho) & 3u) << 4;
 
-  // ---- persistent, XCD-chunked walk over the items (msda_win_common.hpp: queue protocol) ---------------------------
+  // ---- persistent, XCD-chunked walk over the items, software-pipelined across items --------------------------------
+  // Queue protocol as in msda_win_common.hpp (first item static, every further one nslots + the XCD's counter, the fetch
+  // that returns n_x - 1 resets the counter), run TWO items ahead: the index of item i + 1 is published before barrier
+  // (A) of item i, so right behind that barrier every lane knows its next query and ISSUES THE NEXT ITEM'S SAMPLING-
+  // LOCATION LOADS; they stay in flight through staging and gather of item i (32 registers) and item i + 1 starts on
+  // data that has already landed.  (Measured before this change: a workgroup spent a third of an item waiting for these
+  // loads.)  A fetch is made only while the next item is valid, so fetches == items processed still holds.
   const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int chunk = (items + 7) / 8;
   const int item_end = min((xcd + 1) * chunk, items);
-  int item = xcd * chunk + slot0;
+  const unsigned n_x = (unsigned)max(item_end - xcd * chunk, 0);               // items of this XCD
 
-  while (item < item_end) {
-    // ---- the item and this lane's query ------------------------------------------------------------------------------
-    const int m = item % M;
-    const int bt = item / M;
-    const int col = bt % ncol;
-    const int b = bt / ncol;
-    const int cy = col / CX, cx = col - cy * CX;
+  constexpr int NPL = L * 2, NGL = (NPL + 3) / 4;                              // locations: 16-byte pieces, 64-byte groups
+  constexpr int NGW = (L + 3) / 4;                                             // weights: one 16-byte piece per level
 
-    int q = 0;
-    bool valid = false;
-    {
-      int r = tid, q_first = 0;
-      bool found = false, have_first = false;
+  // item -> (image, head) [uniform] and this lane's query (qv = q, or ~q of the query an idle lane shadows)
+  auto decode = [&](const int it, int &b_, int &m_, int &qv_) {
+    const int bt = udiv_by(it, inv_M);
+    m_ = it - bt * M;
+    b_ = udiv_by(bt, inv_ncol);
+    const int col = bt - b_ * ncol;
+    const int cy = udiv_by(col, inv_CX), cx = col - cy * CX;
+    int q = 0, r = tid, q_first = 0;
+    bool found = false, have_first = false;
 #pragma unroll
-      for (int ll = 0; ll < L; ++ll) {
-        const int l = L - 1 - ll;                                             // finest level (last in PCTrans) first
-        const int xa = col_lo(cx, Ws[l], CX), nx = col_lo(cx + 1, Ws[l], CX) - xa;
-        const int ya = col_lo(cy, Hs[l], CY), ny = col_lo(cy + 1, Hs[l], CY) - ya;
-        const int cnt = nx * ny;
-        if (!have_first && cnt > 0) { have_first = true; q_first = St[l] + ya * Ws[l] + xa; }
-        const bool in = !found && r < cnt;
-        if (in) {
-          const int ly = (int)(((float)r + 0.5f) * uni(1.0f / (float)max(nx, 1)));
-          const int lx = r - ly * nx;
-          q = St[l] + (ya + ly) * Ws[l] + xa + lx;
-          found = true;
-        }
-        r -= found ? 0 : cnt;
+    for (int ll = 0; ll < L; ++ll) {
+      const int l = L - 1 - ll;                                               // finest level (last in PCTrans) first
+      const int xa = col_lo_f(cx, Ws[l], CX, inv_2CX), nx = col_lo_f(cx + 1, Ws[l], CX, inv_2CX) - xa;
+      const int ya = col_lo_f(cy, Hs[l], CY, inv_2CY), ny = col_lo_f(cy + 1, Hs[l], CY, inv_2CY) - ya;
+      const int cnt = nx * ny;
+      if (!have_first && cnt > 0) { have_first = true; q_first = St[l] + ya * Ws[l] + xa; }
+      const bool in = !found && r < cnt;
+      if (in) {
+        const int ly = (int)(((float)r + 0.5f) * uni(1.0f / (float)max(nx, 1)));
+        const int lx = r - ly * nx;
+        q = St[l] + (ya + ly) * Ws[l] + xa + lx;
+        found = true;
       }
-      valid = found;
-      if (!found) q = q_first;            // idle lanes shadow a query of the column: they cannot move its boxes
+      r -= found ? 0 : cnt;
     }
-    const long long rec = ((long long)b * S + q) * M + m;
+    qv_ = found ? q : ~q_first;            // idle lanes shadow a query of the column: they cannot move its boxes
+  };
+  // the four queries of this lane's quad (record s of the quad belongs to lane 4 * (lane / 4) + s)
+  auto quad_queries = [&](const int qv_, int (&qs)[4]) {
+    qs[0] = dpp_i<0x00>(qv_);
+    qs[1] = dpp_i<0x55>(qv_);
+    qs[2] = dpp_i<0xAA>(qv_);
+    qs[3] = dpp_i<0xFF>(qv_);
+  };
+  // group g (64 bytes) of the location records of the quad's four queries.  Per-image base pointers are uniform and the
+  // offsets 32-bit (launcher: a per-image tensor stays below 4 GiB), so the loads take the scalar-base + vector-offset
+  // form instead of 64-bit vector address arithmetic.
+  auto issue_loc_group = [&](auto gc, const int b_, const int m_, const int qv_, col_f32x4 (&raw)[NGL][4]) {
+    constexpr int g = decltype(gc)::value;
+    int qs[4];
+    quad_queries(qv_, qs);
+    const float *base = loc + (long long)b_ * S * M * (L * P * 2);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      int pi = g * 4 + ((s4 - qi) & 3);
+      if (NPL % 4 != 0 && pi >= NPL) pi = g * 4;                               // (a partial last group: harmless repeat)
+      const unsigned r = (unsigned)((qs[s4] < 0 ? ~qs[s4] : qs[s4]) * M + m_);
+      raw[g][s4] = *reinterpret_cast<const col_f32x4 *>(base + (size_t)(r * (unsigned)(L * P * 2) + (unsigned)(pi * 4)));
+    }
+  };
+  auto issue_loc = [&](const int b_, const int m_, const int qv_, col_f32x4 (&raw)[NGL][4]) {
+    [&]<int... Gs>(std::integer_sequence<int, Gs...>) {
+      (issue_loc_group(std::integral_constant<int, Gs>{}, b_, m_, qv_, raw), ...);
+    }(std::make_integer_sequence<int, NGL>{});
+  };
+  // FUSED: the query's reference points (one (x, y) per level), fetched with the record
+  auto issue_ref = [&](const int b_, const int qv_, col_f32x2 (&rr)[L]) {
+    if constexpr (FUSED) {
+      const float *rrow = ref + b_ * ref_batch_stride;
+      const unsigned o = (unsigned)(qv_ < 0 ? ~qv_ : qv_) * (unsigned)(L * 2);
+#pragma unroll
+      for (int l = 0; l < L; ++l) rr[l] = *reinterpret_cast<const col_f32x2 *>(rrow + (size_t)(o + 2u * l));
+    }
+  };
 
-    // ---- the record: sampling locations (FUSED: reference point + offset / (W, H)) ---------------------------------
+  int item = xcd * chunk + slot0;
+  bool have = item < item_end;
+  int b = 0, m = 0, qv = 0;
+  col_f32x4 raw[NGL][4];
+  // (thread 0) the counter value fetched last lives in LDS word next_idx[1], not in a register: a register alive across
+  // the whole item was spilled by the compiler, and spilling an atomic's result means waiting for it on the spot
+  if (have) {
+    decode(item, b, m, qv);
+    issue_loc(b, m, qv, raw);
+    if (queue && tid == 0) next_idx[1] = atomicAdd(queue + xcd, 1u);
+  }
+
+  stamp(-1);
+  while (have) {
+    // (opaque per iteration: the compiler otherwise hoists every per-lane expression of tid / qi out of the item loop --
+    // a dozen 64-bit piece offsets, float copies of tid, ... -- and spills them)
+    asm volatile("" : "+v"(tid), "+v"(qi));
+    const bool valid = qv >= 0;
+    const int q = valid ? qv : ~qv;
+    const long long rec_img = (long long)b * S;
+    int qs[4];
+    quad_queries(qv, qs);
+
+    // FUSED: the reference points sit in L2 (shared by the heads and the batch): fetched here, not a whole item ahead
+    // (eight more registers alive across the gather spilled); the transposition below runs while they arrive
+    col_f32x2 rr[L];
+    issue_ref(b, qv, rr);
+    // ---- the record: sampling locations (FUSED: reference point + offset / (W, H)), loaded one item ago ----------------
     col_f32x2 lxy[L][P];
     {
-      const col_f32x4 *lp = reinterpret_cast<const col_f32x4 *>(loc + rec * (L * P * 2));
-      col_f32x4 raw[L * 2];
 #pragma unroll
-      for (int i = 0; i < L * 2; ++i) raw[i] = lp[i];
-      col_f32x2 rr[L];
-      if constexpr (FUSED) {
-        const float *rrow = ref + b * ref_batch_stride + (long long)q * (L * 2);
-#pragma unroll
-        for (int l = 0; l < L; ++l) rr[l] = *reinterpret_cast<const col_f32x2 *>(rrow + 2 * l);
-      }
+      for (int g = 0; g < NGL; ++g) quad_transpose_in(raw[g], qi0, qi1);
 #pragma unroll
       for (int l = 0; l < L; ++l)
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-          col_f32x2 v = {raw[l * 2 + k / 2][(k & 1) * 2], raw[l * 2 + k / 2][(k & 1) * 2 + 1]};
-          if constexpr (FUSED) v = col_f32x2{fmaf(v[0], invW[l], rr[l][0]), fmaf(v[1], invH[l], rr[l][1])};
-          lxy[l][k] = v;
+          const col_f32x4 pc = raw[(l * 2 + k / 2) / 4][(l * 2 + k / 2) & 3];
+          col_f32x2 v = {pc[(k & 1) * 2], pc[(k & 1) * 2 + 1]};
+          if constexpr (FUSED) v = __builtin_elementwise_fma(v, invWH[l], rr[l]);
+          // from here on the PIXEL coordinates (w_im, h_im) = loc * (W, H) - 0.5 (cuh:283-288), formed once for the
+          // boxes and the gather (packed FMAs: x and y in one instruction)
+          lxy[l][k] = __builtin_elementwise_fma(v, fWH[l], col_f32x2{-0.5f, -0.5f});
         }
+    }
+
+    // (everything that waits for the reference-point loads must be complete before the atomic below is issued)
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int k = 0; k < P; ++k) asm volatile("" : "+v"(lxy[l][k]));
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- publish the next item's index, fetch the one after it (its value is parked in LDS behind the staging barrier).
+    // Issued behind the loads the pre-pass waits for: the memory counter is in-order, a wait for those would include it. ---
+    unsigned f_new = 0u;
+    bool fetched = false;
+    if (tid == 0) {
+      unsigned nxt = (unsigned)(item - xcd * chunk + nslots);                 // static stride when there is no queue
+      if (queue) {
+        const unsigned f_next = next_idx[1];
+        if (f_next + 1u >= n_x)                                               // that was the launch's last fetch
+          __hip_atomic_store(queue + xcd, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nxt = (unsigned)nslots + f_next;
+        if (nxt < n_x) {
+          // (inline asm: the compiler waits for a returning atomic at the end of this divergent block -- a full round
+          // trip to L2 in front of the pre-pass; the wait now sits where the value is parked, behind the pre-pass)
+          const unsigned one = 1u, zero = 0u;
+          const unsigned *qp = queue + xcd;
+          // (s_nop: the base may just have been restored by v_readlane; a vector-memory instruction reading a scalar
+          // register a vector instruction wrote needs 5 wait states, and the hazard recogniser does not see into inline asm)
+          asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0"
+                       : "=v"(f_new) : "v"(zero), "v"(one), "s"(qp) : "memory");
+          fetched = true;
+        }
+      }
+      next_idx[0] = nxt;
     }
 
     // ---- pre-pass: per-level bounding box (first corners, biased by +1; the box covers x0 .. x0 + 1) ----------------
@@ -193,10 +377,10 @@ __global__ __launch_bounds__(BLOCK) void msda_forward_col_kernel(
       float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
 #pragma unroll
       for (int k = 0; k < P; ++k) {
-        // same expressions as the gather's, so both sides floor the same number.  A sample is gated in iff
+        // the very registers the gather floors.  A sample is gated in iff
         // -1 < w_im < W: clamping to [-1, W - 0.5] maps a gated-out coordinate onto one a gated-in sample could have
         // (NaN clamps to -1), so it can only widen the box towards the map border, never past the 1-pixel apron.
-        const float h_im = fmaf(lxy[l][k][1], fH[l], -0.5f), w_im = fmaf(lxy[l][k][0], fW[l], -0.5f);
+        const float h_im = lxy[l][k][1], w_im = lxy[l][k][0];
         const float wc = __builtin_amdgcn_fmed3f(w_im, -1.f, uni(fW[l] - 0.5f));
         const float hc = __builtin_amdgcn_fmed3f(h_im, -1.f, uni(fH[l] - 0.5f));
         mnx = fminf(mnx, wc);
@@ -213,20 +397,44 @@ __global__ __launch_bounds__(BLOCK) void msda_forward_col_kernel(
         bb[(wave * L + l) * 2 + 1] = hi;
       }
     }
+    __builtin_amdgcn_sched_barrier(0);                                        // (keep the address arithmetic below down here)
+    // ---- this item's weights (FUSED: logits): fetched now, looked at after the staging barrier.  (Behind the pre-pass:
+    // anything that waits on the memory counter there -- it is in-order -- would otherwise wait for these loads too.) ---------
+    col_f32x4 wraw[NGW][4];
+    {
+      const float *wbase_img = attn + rec_img * M * (L * P);
+#pragma unroll
+      for (int g = 0; g < NGW; ++g)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          int pi = g * 4 + ((s4 - qi) & 3);
+          if (L % 4 != 0 && pi >= L) pi = g * 4;
+          const unsigned r = (unsigned)((qs[s4] < 0 ? ~qs[s4] : qs[s4]) * M + m);
+          wraw[g][s4] = *reinterpret_cast<const col_f32x4 *>(wbase_img + (size_t)(r * (unsigned)(L * P) + (unsigned)(pi * 4)));
+        }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // boxes in LDS before the barrier
+    stamp(0);
     __syncthreads();                                                          // (A) boxes visible; pool free
+    stamp(1);
 
-    unsigned rfetch = 0u;
-    if (queue && tid == 0) rfetch = atomicAdd(queue + xcd, 1u);
+    // ---- the next item: its query per lane, its location loads issued (in flight until the next iteration) --------------
+    int item_n, b_n = 0, m_n = 0, qv_n = 0;
+    {
+      const unsigned nxt = __builtin_amdgcn_readfirstlane(next_idx[0]);
+      item_n = nxt < n_x ? xcd * chunk + (int)nxt : item_end;                // never out of the chunk
+    }
+    const bool have_n = item_n < item_end;             // (decoded once this item's first staging is issued, below)
 
     // ---- windows and phases (uniform) --------------------------------------------------------------------------------
     int wx0[L], wy0[L], wwid[L], whgt[L], wsize[L], wbase[L], phase_of[L];
-    int nph;
+    bool starts_phase[L];
     {
 #pragma unroll
       for (int l = 0; l < L; ++l) {
-        unsigned lo = lane < NW ? bb[(lane * L + l) * 2] : 0xFFFFFFFFu;
-        unsigned hi = lane < NW ? bb[(lane * L + l) * 2 + 1] : 0u;
+        const int ln = tid & 63;                                               // (from the per-iteration opaque tid: not hoisted)
+        unsigned lo = ln < NW ? bb[(ln * L + l) * 2] : 0xFFFFFFFFu;
+        unsigned hi = ln < NW ? bb[(ln * L + l) * 2 + 1] : 0u;
         lo = __builtin_amdgcn_readfirstlane(wave_reduce_pk<true>(lo));
         hi = __builtin_amdgcn_readfirstlane(wave_reduce_pk<false>(hi));
         const int x0 = (int)(lo & 0xFFFFu) - 1, y0 = (int)(lo >> 16) - 1;    // un-bias: origin may be -1 (apron)
@@ -238,10 +446,14 @@ __global__ __launch_bounds__(BLOCK) void msda_forward_col_kernel(
         whgt[l] = empty ? 0 : y1 - y0 + 1;
         wsize[l] = wwid[l] * whgt[l];
       }
+      // levels are gathered in a fixed order, finest (last) first; a level that does not fit beside the ones already
+      // planned opens a new PHASE: the pool is re-staged right before it (two barriers)
       int ph = 0, used = 0;
+      bool fresh = true;
 #pragma unroll
       for (int ll = 0; ll < L; ++ll) {
         const int l = L - 1 - ll;
+        starts_phase[l] = false;
         if (wsize[l] > pool_px - 2) {                                          // never fits: gathered from global memory
           phase_of[l] = -1;
           wbase[l] = 0;
@@ -250,27 +462,19 @@ __global__ __launch_bounds__(BLOCK) void msda_forward_col_kernel(
         if (used + wsize[l] > pool_px - 2) {
           ++ph;
           used = 0;
+          fresh = true;
         }
         phase_of[l] = ph;
+        starts_phase[l] = fresh;
+        fresh = false;
         wbase[l] = used + 2;                                                   // pixels 0, 1 are the zero pixels
         used += wsize[l];
       }
-      nph = ph + 1;
     }
 
-    // ---- weights (FUSED: logits -> softmax).  Issued here, consumed after the first staging barrier ------------------
     float wts[L][P];
-    {
-      const col_f32x4 *wp = reinterpret_cast<const col_f32x4 *>(attn + rec * (L * P));
-#pragma unroll
-      for (int l = 0; l < L; ++l) {
-        const col_f32x4 t = wp[l];
-#pragma unroll
-        for (int k = 0; k < P; ++k) wts[l][k] = t[k];
-      }
-    }
-
-    const float *vimg = value + (long long)b * S * MD + m * D;               // this image, this head
+    stamp(2);
+    const float *vimg = value + rec_img * MD + m * D;                        // this image, this head
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value + (long long)b * S * MD), 0,
                                                         (int)((unsigned)S * (unsigned)MD * 4u), 0x00020000);
 
@@ -278,124 +482,145 @@ __global__ __launch_bounds__(BLOCK) void msda_forward_col_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j][0] = acc[j][1] = col_f32x2{0.f, 0.f};
 
-    // one sample from LDS (LDS = true) or through the buffer descriptor (LDS = false)
-    auto sample = [&](auto lc, auto kc, auto lds_c) {
+    // (the empty asm pins the accumulators: without it the compiler sinks a level's 128 packed FMAs below the LDS reads of
+    // all four samples and spills the 256 data registers in between)
+    auto pin_acc = [&]() {
+      asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]),
+                        "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
+    };
+    // two corners of one pixel row: corner-major, so consecutive packed FMAs go to different accumulators (8 chains)
+    auto fma_row = [&](const col_f32x4 (&va)[4], const col_f32x4 (&vb)[4], const float wa, const float wb) {
+      const col_f32x2 wwa = {wa, wa}, wwb = {wb, wb};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          acc[j][e] = __builtin_elementwise_fma(wwa, col_f32x2{va[j][2 * e], va[j][2 * e + 1]}, acc[j][e]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          acc[j][e] = __builtin_elementwise_fma(wwb, col_f32x2{vb[j][2 * e], vb[j][2 * e + 1]}, acc[j][e]);
+    };
+    // a sample's geometry: gate (cuh:290-296), first corner, the four bilinear * attention weights
+    struct Geo {
+      col_f32x2 g12, g34;                 // (hh * hw, hh * lw) * w and (lh * hw, lh * lw) * w
+      int x0, y0;
+      bool gate;
+    };
+    auto geometry = [&](auto lc, auto kc) {
       constexpr int l = decltype(lc)::value;
       constexpr int k = decltype(kc)::value;
-      constexpr bool LDS = decltype(lds_c)::value;
-      const int H = Hs[l], W = Ws[l];
-      // (opaque copies: without them the compiler hoists every sample's geometry out of the phase loop -- it is
-      // invariant there -- and shares it with the pre-pass, ~200 live registers, hundreds of spills)
-      float sx = lxy[l][k][0], sy = lxy[l][k][1];
-      asm volatile("" : "+v"(sx), "+v"(sy));
-      const float h_im = fmaf(sy, fH[l], -0.5f), w_im = fmaf(sx, fW[l], -0.5f);
-      const bool gate = valid && h_im > -1 && w_im > -1 && h_im < fH[l] && w_im < fW[l];   // false for NaN (cuh:290-296)
-      const float hf = floorf(h_im), wf = floorf(w_im);
-      const int y0 = gate ? (int)hf : 0, x0 = gate ? (int)wf : 0;
-      const float lh = gate ? h_im - hf : 0.f, lw = gate ? w_im - wf : 0.f;
-      const float wgt = gate ? wts[l][k] : 0.f;
-      const float hh = 1.f - lh, hw = 1.f - lw;
-      const float g1 = hh * hw * wgt, g2 = hh * lw * wgt, g3 = lh * hw * wgt, g4 = lh * lw * wgt;
-      const col_f32x2 ww1 = {g1, g1}, ww2 = {g2, g2}, ww3 = {g3, g3}, ww4 = {g4, g4};
-      // one pixel ROW of the sample at a time (two corners = 8 x 16 B per lane in flight): the other three waves of the
-      // SIMD cover the LDS latency, and 32 data registers instead of 64 keep the kernel inside its 128-VGPR budget.
-      // Corner-major FMAs: consecutive packed FMAs go to different accumulators (8 independent chains).
-      // (the empty asm pins the accumulators: without it the compiler sinks a level's 128 packed FMAs below the LDS reads
-      // of all four samples and spills the 256 data registers in between)
-      auto pin_acc = [&]() {
-        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]),
-                          "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
-      };
-      auto fma_row = [&](const col_f32x4 (&va)[4], const col_f32x4 (&vb)[4], const col_f32x2 wa, const col_f32x2 wb) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int e = 0; e < 2; ++e)
-            acc[j][e] = __builtin_elementwise_fma(wa, col_f32x2{va[j][2 * e], va[j][2 * e + 1]}, acc[j][e]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int e = 0; e < 2; ++e)
-            acc[j][e] = __builtin_elementwise_fma(wb, col_f32x2{vb[j][2 * e], vb[j][2 * e + 1]}, acc[j][e]);
-      };
-      if constexpr (LDS) {
-        // all four corners lie inside the staged window (out-of-map ones are zeros); a gated-out sample reads the
-        // two zero pixels (offset 0, row step 0)
-        const unsigned a = gate ? (unsigned)(wbase[l] + __mul24(y0 - wy0[l], wwid[l]) + (x0 - wx0[l])) << 6 : 0u;
-        const unsigned rowb = gate ? (unsigned)wwid[l] << 6 : 0u;
-        {
-          col_f32x4 va[4], vb[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const unsigned char *pa = pool + (a + rot[j]);
-            va[j] = *reinterpret_cast<const col_f32x4 *>(pa);
-            vb[j] = *reinterpret_cast<const col_f32x4 *>(pa + PXB);
-          }
-          fma_row(va, vb, ww1, ww2);
-        }
-        pin_acc();
-        __builtin_amdgcn_sched_barrier(0);
-        {
-          col_f32x4 va[4], vb[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const unsigned char *pb = pool + (a + rowb + rot[j]);
-            va[j] = *reinterpret_cast<const col_f32x4 *>(pb);
-            vb[j] = *reinterpret_cast<const col_f32x4 *>(pb + PXB);
-          }
-          fma_row(va, vb, ww3, ww4);
-        }
-        pin_acc();
-        __builtin_amdgcn_sched_barrier(0);
-      } else {
-        constexpr unsigned OOB = 0x80000000u;                                  // S * M * D * 4 < 2^31 (C ABI check)
-        const bool top = gate && y0 >= 0, bot = gate && y0 + 1 <= H - 1;
-        const bool lft = x0 >= 0, rgt = x0 + 1 <= W - 1;
-        const unsigned MDb = (unsigned)MD * 4u;
-        const unsigned a = (unsigned)(St[l] + y0 * W + x0) * MDb + (unsigned)(m * D) * 4u;
-        const unsigned o1 = (top && lft) ? a : OOB, o2 = (top && rgt) ? a + MDb : OOB;
-        const unsigned o3 = (bot && lft) ? a + (unsigned)W * MDb : OOB, o4 = (bot && rgt) ? a + (unsigned)W * MDb + MDb : OOB;
-        {
-          col_f32x4 va[4], vb[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            va[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o1 + rot[j]), 0, 0));
-            vb[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o2 + rot[j]), 0, 0));
-          }
-          fma_row(va, vb, ww1, ww2);
-        }
-        pin_acc();
-        __builtin_amdgcn_sched_barrier(0);
-        {
-          col_f32x4 va[4], vb[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            va[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o3 + rot[j]), 0, 0));
-            vb[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o4 + rot[j]), 0, 0));
-          }
-          fma_row(va, vb, ww3, ww4);
-        }
-        pin_acc();
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      // (opaque: without it the compiler hoists every sample's geometry to the top of the item and keeps it alive)
+      col_f32x2 pix = lxy[l][k];
+      asm volatile("" : "+v"(pix));
+      Geo g;
+      g.gate = pix[1] > -1 && pix[0] > -1 && pix[1] < fH[l] && pix[0] < fW[l];    // false for NaN
+      // a gated-out sample (possibly Inf / NaN coordinates) becomes pixel (0, 0) with weight 0, reading the zero pixels
+      pix[0] = g.gate ? pix[0] : 0.f;
+      pix[1] = g.gate ? pix[1] : 0.f;
+      const float wgt = g.gate ? wts[l][k] : 0.f;
+      const col_f32x2 flo = {floorf(pix[0]), floorf(pix[1])};
+      g.x0 = (int)flo[0];
+      g.y0 = (int)flo[1];
+      const col_f32x2 lo = pix - flo;                                          // (lw, lh)
+      const col_f32x2 hi = col_f32x2{1.f, 1.f} - lo;                           // (hw, hh)
+      const col_f32x2 t = {hi[0] * wgt, lo[0] * wgt};                          // (hw, lw) * w
+      g.g12 = t * col_f32x2{hi[1], hi[1]};
+      g.g34 = t * col_f32x2{lo[1], lo[1]};
+      return g;
     };
-    auto gather_level = [&](auto lc, auto lds_c) {
+
+    // One level from its LDS window, one pixel ROW of a sample at a time (two corners = 8 x 16 B per lane in flight): the
+    // other waves of the SIMD cover the LDS latency.  (A rolling pipeline with the next row's reads in flight during the
+    // FMAs needs 32 more data registers than the 168 of three workgroups per CU leave: it spilled and was slower.)
+    // All four corners lie inside the staged window (out-of-map ones are zeros); a gated-out sample reads the two zero
+    // pixels (offset 0, row step 0).
+    auto gather_level_lds = [&](auto lc) {
+      constexpr int l = decltype(lc)::value;
       [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
-        (sample(lc, std::integral_constant<int, Ks>{}, lds_c), ...);
+        ([&] {
+          const Geo g = geometry(lc, std::integral_constant<int, Ks>{});
+          const unsigned a = g.gate ? (unsigned)(wbase[l] + __mul24(g.y0 - wy0[l], wwid[l]) + (g.x0 - wx0[l])) << 6 : 0u;
+          const unsigned rowb = g.gate ? (unsigned)wwid[l] << 6 : 0u;
+          {
+            col_f32x4 va[4], vb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const unsigned char *pa = pool + (a + rot[j]);
+              va[j] = *reinterpret_cast<const col_f32x4 *>(pa);
+              vb[j] = *reinterpret_cast<const col_f32x4 *>(pa + PXB);
+            }
+            fma_row(va, vb, g.g12[0], g.g12[1]);
+          }
+          pin_acc();
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            col_f32x4 va[4], vb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const unsigned char *pb = pool + (a + rowb + rot[j]);
+              va[j] = *reinterpret_cast<const col_f32x4 *>(pb);
+              vb[j] = *reinterpret_cast<const col_f32x4 *>(pb + PXB);
+            }
+            fma_row(va, vb, g.g34[0], g.g34[1]);
+          }
+          pin_acc();
+          __builtin_amdgcn_sched_barrier(0);
+        }(), ...);
+      }(std::make_integer_sequence<int, P>{});
+    };
+    // ... or through the buffer descriptor (a level whose box exceeds the pool): out-of-map corners get an out-of-range
+    // offset and read zeros
+    auto gather_level_global = [&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      const int H = Hs[l], W = Ws[l];
+      [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+        ([&] {
+          const Geo g = geometry(lc, std::integral_constant<int, Ks>{});
+          constexpr unsigned OOB = 0x80000000u;                                // S * M * D * 4 < 2^31 (C ABI check)
+          const bool top = g.gate && g.y0 >= 0, bot = g.gate && g.y0 + 1 <= H - 1;
+          const bool lft = g.x0 >= 0, rgt = g.x0 + 1 <= W - 1;
+          const unsigned MDb = (unsigned)MD * 4u;
+          const unsigned a = (unsigned)(St[l] + g.y0 * W + g.x0) * MDb + (unsigned)(m * D) * 4u;
+          const unsigned o1 = (top && lft) ? a : OOB, o2 = (top && rgt) ? a + MDb : OOB;
+          const unsigned o3 = (bot && lft) ? a + (unsigned)W * MDb : OOB, o4 = (bot && rgt) ? a + (unsigned)W * MDb + MDb : OOB;
+          {
+            col_f32x4 va[4], vb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              va[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o1 + rot[j]), 0, 0));
+              vb[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o2 + rot[j]), 0, 0));
+            }
+            fma_row(va, vb, g.g12[0], g.g12[1]);
+          }
+          pin_acc();
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            col_f32x4 va[4], vb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              va[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o3 + rot[j]), 0, 0));
+              vb[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o4 + rot[j]), 0, 0));
+            }
+            fma_row(va, vb, g.g34[0], g.g34[1]);
+          }
+          pin_acc();
+          __builtin_amdgcn_sched_barrier(0);
+        }(), ...);
       }(std::make_integer_sequence<int, P>{});
     };
 
-    for (int ph = 0; ph < nph; ++ph) {
-      if (ph > 0) __syncthreads();                                            // every wave is done with the pool
-      // ---- stage this phase's boxes by LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, every piece in flight
-      // at once; LDS address of a piece = wave-uniform base + lane * 16; the global source is per lane (apron lanes read
-      // a 16-byte zero constant) -----------------------------------------------------------------------------------------
+    // stage the windows of one phase: LDS-DMA (buffer_load_dwordx4 ... lds), no VGPR round trip, every piece in flight at
+    // once; LDS address of a piece = wave-uniform base + lane * 16; the global source is a per-lane 32-bit offset into this
+    // image's buffer descriptor
+    auto stage_phase = [&](const int phx) {
 #pragma unroll
       for (int l = 0; l < L; ++l) {
-        if (phase_of[l] == ph && wsize[l] > 0) {
+        if (phase_of[l] == phx && wsize[l] > 0) {
           const float inv_w = uni(1.0f / (float)wwid[l]);
           const int n16 = wsize[l] * 4;
-          const float *vlev = vimg + (long long)St[l] * MD;
+          const unsigned lvl_off = (unsigned)St[l] * (unsigned)MD * 4u + (unsigned)(m * D) * 4u;   // bytes, this head
           unsigned char *dst = pool + (size_t)wbase[l] * PXB;
           for (int it = 0; it * BLOCK < n16; ++it) {
             const int i = it * BLOCK + tid;
@@ -403,71 +628,128 @@ __global__ __launch_bounds__(BLOCK) void msda_forward_col_kernel(
               const int px = i >> 2, cc = i & 3;
               const int r = (int)(((float)px + 0.5f) * inv_w);
               const int y = wy0[l] + r, x = wx0[l] + px - r * wwid[l];
-              const bool inside = y >= 0 && y < Hs[l] && x >= 0 && x < Ws[l];
-              const float *src = inside ? vlev + (long long)(y * Ws[l] + x) * MD + cc * 4 : g_zero16;
-              __builtin_amdgcn_global_load_lds(
-                  (const __attribute__((address_space(1))) void *)(src),
-                  (__attribute__((address_space(3))) void *)(dst + (size_t)(it * BLOCK + (tid & ~63)) * 16), 16, 0, 0);
+              // apron texels (outside the map) get an out-of-range offset: the descriptor's bounds check returns zeros
+              const bool inside = (unsigned)y < (unsigned)Hs[l] && (unsigned)x < (unsigned)Ws[l];
+              const unsigned off = inside ? lvl_off + (unsigned)(y * Ws[l] + x) * ((unsigned)MD * 4u) + (unsigned)(cc * 16)
+                                          : 0x80000000u;
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                  rsrc, (__attribute__((address_space(3))) void *)(dst + (size_t)(it * BLOCK + (tid & ~63)) * 16), 16,
+                  (int)off, 0, 0, 0);
             }
           }
         }
       }
-      if (ph == 0 && tid == 0) {
-        unsigned fetched = (unsigned)(item - xcd * chunk + nslots);           // static stride when there is no queue
-        if (queue) {
-          if (rfetch + 1u >= (unsigned)(item_end - xcd * chunk)) atomicExch(queue + xcd, 0u);
-          fetched = (unsigned)nslots + rfetch;
-        }
-        next_idx[0] = fetched;
+    };
+    auto front_end = [&]() {                                                  // the weights, once they are needed
+#pragma unroll
+      for (int g = 0; g < NGW; ++g) quad_transpose_in(wraw[g], qi0, qi1);
+#pragma unroll
+      for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int k = 0; k < P; ++k) wts[l][k] = wraw[l / 4][l & 3][k];
+      if constexpr (FUSED) {                                                  // softmax over the record's L * P logits
+        float mx = -INFINITY;
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+          for (int k = 0; k < P; ++k) mx = fmaxf(mx, wts[l][k]);
+        float sum = 0.f;
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+          for (int k = 0; k < P; ++k) {
+            wts[l][k] = __expf(wts[l][k] - mx);
+            sum += wts[l][k];
+          }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+          for (int k = 0; k < P; ++k) wts[l][k] *= inv;
       }
-      __syncthreads();                                                        // windows staged (vmcnt(0) + barrier)
+    };
 
-      if (ph == 0) {
-        if constexpr (FUSED) {                                                // softmax over the record's L * P logits
-          float mx = -INFINITY;
-#pragma unroll
-          for (int l = 0; l < L; ++l)
-#pragma unroll
-            for (int k = 0; k < P; ++k) mx = fmaxf(mx, wts[l][k]);
-          float sum = 0.f;
-#pragma unroll
-          for (int l = 0; l < L; ++l)
-#pragma unroll
-            for (int k = 0; k < P; ++k) {
-              wts[l][k] = __expf(wts[l][k] - mx);
-              sum += wts[l][k];
-            }
-          const float inv = 1.f / sum;
-#pragma unroll
-          for (int l = 0; l < L; ++l)
-#pragma unroll
-            for (int k = 0; k < P; ++k) wts[l][k] *= inv;
+    auto level_step = [&](auto llc) {
+      constexpr int ll = decltype(llc)::value;
+      constexpr int l = L - 1 - ll;
+      if (starts_phase[l]) {
+        if (ll > 0) __syncthreads();                                          // every wave is done with the pool
+        stage_phase(phase_of[l]);
+        if constexpr (ll == 0) {
+          if (have_n) decode(item_n, b_n, m_n, qv_n);                          // while the LDS-DMA pieces are in flight
         }
+        if (ll == 0) stamp(3);
+        __syncthreads();                                                      // windows staged (vmcnt(0) + barrier)
+        if (ll == 0) stamp(4);
+      }
+      if constexpr (ll == 0) {
+        // (thread 0) park the counter value fetched at the top of the item: the weights below need the memory counter at
+        // zero anyway, so this wait is free -- anywhere earlier it would stall on the loads issued since
+        if (fetched) {
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(f_new)::"memory");
+          next_idx[1] = f_new;
+        }
+        front_end();
+      }
+      if (phase_of[l] >= 0) gather_level_lds(std::integral_constant<int, l>{});
+      else gather_level_global(std::integral_constant<int, l>{});             // box larger than the pool: global memory
+      // one group of the next item's location record per level: its registers are the ones this level's points freed
+      if constexpr (ll < NGL) {
+        if (have_n) issue_loc_group(std::integral_constant<int, ll>{}, b_n, m_n, qv_n, raw);
       }
 
-      [&]<int... Ls>(std::integer_sequence<int, Ls...>) {
-        ((phase_of[L - 1 - Ls] == ph ? gather_level(std::integral_constant<int, L - 1 - Ls>{}, std::true_type{}) : (void)0), ...);
-      }(std::make_integer_sequence<int, L>{});
+    };
+    if (!starts_phase[L - 1]) {                                               // (the finest level is gathered from global)
+      if (have_n) decode(item_n, b_n, m_n, qv_n);
+      stamp(3);
+      stamp(4);
     }
-    // levels whose box exceeds the pool: straight from global memory (every lane, uniform branch)
-    [&]<int... Ls>(std::integer_sequence<int, Ls...>) {
-      ((phase_of[Ls] < 0 ? gather_level(std::integral_constant<int, Ls>{}, std::false_type{}) : (void)0), ...);
+    [&]<int... LLs>(std::integer_sequence<int, LLs...>) {
+      (level_step(std::integral_constant<int, LLs>{}), ...);
     }(std::make_integer_sequence<int, L>{});
+    static_assert(NGL <= L, "one location group per level");
 
-    if (valid) {
-      float *op = out + rec * D;
+    stamp(5);
+    {
+      // store, quad-cooperatively: register j of lane c holds piece (j + rho) % 4 of ITS record (rho is the same in the
+      // whole quad).  A quad_perm rotation by k hands lane i the register k of lane (i - k) % 4; rotating the four received
+      // registers by -i puts the one that came from lane s into slot s: piece (i - s + rho) % 4 of record s.  Store
+      // instruction s then writes the 64 consecutive bytes of record s from the quad's four lanes.
+      col_f32x4 u[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<col_f32x4 *>(reinterpret_cast<unsigned char *>(op) + rot[j]) =
-            col_f32x4{acc[j][0][0], acc[j][0][1], acc[j][1][0], acc[j][1][1]};
+      for (int j = 0; j < 4; ++j) u[j] = col_f32x4{acc[j][0][0], acc[j][0][1], acc[j][1][0], acc[j][1][1]};
+      u[1] = quad_rot<1>(u[1]);
+      u[2] = quad_rot<2>(u[2]);
+      u[3] = quad_rot<3>(u[3]);
+      // slot s <- received register (i - s) % 4: reverse the order (compile time), then rotate by (-i) % 4
+      col_f32x4 w4[4] = {u[0], u[3], u[2], u[1]};
+      rot_regs(w4, qi0, qn1);
+      int qo[4];
+      quad_queries(qv, qo);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        if (qo[s4] >= 0) {
+          float *op = out + rec_img * M * D +
+                      (size_t)((unsigned)(qo[s4] * M + m) * (unsigned)D + (unsigned)((((qi - s4) + (int)rho) & 3) * 4));
+          *reinterpret_cast<col_f32x4 *>(op) = w4[s4];
+        }
+      }
     }
 
-    {                                                                          // (written before the staging barrier)
-      const unsigned nxt = __builtin_amdgcn_readfirstlane(next_idx[0]);
-      item = nxt < (unsigned)(item_end - xcd * chunk) ? xcd * chunk + (int)nxt : item_end;   // never out of the chunk
-    }
+    item = item_n;
+    have = have_n;
+    b = b_n;
+    m = m_n;
+    qv = qv_n;
+    stamp(6);
+  }
+  if constexpr (STAMP) {
+    if (tid == 0 && stamps)
+      for (int i = 0; i < 8; ++i) stamps[(size_t)blockIdx.x * 8 + i] = t_sum[i];
   }
 }
+
+unsigned long long *win_stamp_buffer();                                      // msda_forward_win.hip (diagnostic)
 
 // ---- launcher: returns -100 when this geometry is not covered (caller uses another kernel) ----------------------------
 // ref == nullptr: plain op; ref != nullptr: fused front-end (loc = raw offsets, attn = raw logits).
@@ -479,25 +761,46 @@ int launch_msda_forward_col(const void *value, const int64_t *shapes, const int6
   if (ref && (((uintptr_t)ref) & 7u)) return -100;
   if (D != 16 || P != 4 || L < 3 || L > 5 || Lq != S || M < 1) return -100;
   if ((long long)N * ((long long)S + 4096) * M >= 0x7fffffffLL) return -100;   // item / record arithmetic headroom
-  constexpr int BLOCK = 1024;
-  static const int pool_kb = [] { const char *e = getenv("PCT_COL_POOL_KB"); const int v = e ? atoi(e) : 0;
-                                  return (v >= 32 && v <= 158) ? v : 150; }();
+  if ((long long)S * M * L * P * 8 >= 0xffffffffLL) return -100;               // 32-bit byte offsets inside an image
+  // threads per workgroup x workgroups per CU: 1024 x 1 (~150 KB pool, 128 registers), 512 x 2 (~75 KB each, 128 registers),
+  // 384 x 2 (~75 KB, 168 registers), 256 x 3 (~50 KB, 168 registers).  With more than one workgroup per CU the memory
+  // phases of one (records, staging) overlap the gather of the others.
+  static const int block_env = [] { const char *e = getenv("PCT_COL_BLOCK"); const int v = e ? atoi(e) : 0;
+                                    return (v == 256 || v == 384 || v == 512 || v == 1024) ? v : 256; }();
+  static const int pool_env = [] { const char *e = getenv("PCT_COL_POOL_KB"); return e ? atoi(e) : 0; }();
+  const int BLOCKV = block_env;
+  const int wg_per_cu = BLOCKV == 1024 ? 1 : (BLOCKV == 256 ? 3 : 2);
+  const int pool_max = BLOCKV == 1024 ? 158 : (BLOCKV == 256 ? 52 : 78);
+  const int pool_kb = (pool_env >= 16 && pool_env <= pool_max) ? pool_env : (BLOCKV == 1024 ? 150 : (BLOCKV == 256 ? 50 : 74));
   const int pool_px = pool_kb * 1024 / 64;
-  const size_t lds = (size_t)pool_px * 64 + ((size_t)(BLOCK / 64) * L * 2 + 4) * sizeof(unsigned);
-  const dim3 grid(256), block(BLOCK);
+  const size_t lds = (size_t)pool_px * 64 + ((size_t)(BLOCKV / 64) * L * 2 + 4) * sizeof(unsigned);   // pool, boxes, queue words
+  const dim3 grid(256 * wg_per_cu), block(BLOCKV);
   unsigned *queue = win_queue_slot(stream);                                    // nullptr: static item stride
   const float *v = static_cast<const float *>(value);
   const float *lc = static_cast<const float *>(loc), *at = static_cast<const float *>(attn);
   float *o = static_cast<float *>(out);
-#define PCT_COL(L_, FU_)                                                                                                \
+#define PCT_COL_K(L_, FU_, B_, ST_)                                                                                     \
   do {                                                                                                                  \
     static const hipError_t attr_rc = hipFuncSetAttribute(                                                              \
-        reinterpret_cast<const void *>(&msda_forward_col_kernel<L_, FU_, BLOCK>),                                       \
+        reinterpret_cast<const void *>(&msda_forward_col_kernel<L_, FU_, B_, ST_>),                                     \
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                                        \
     if (attr_rc != hipSuccess) return (int)attr_rc;                                                                     \
-    hipLaunchKernelGGL((msda_forward_col_kernel<L_, FU_, BLOCK>), grid, block, lds, stream, v, shapes, starts, lc, at,  \
-                       N, S, M, pool_px, o, ref, ref_batch_stride, queue);                                              \
+    hipLaunchKernelGGL((msda_forward_col_kernel<L_, FU_, B_, ST_>), grid, block, lds, stream, v, shapes, starts, lc,    \
+                       at, N, S, M, pool_px, o, ref, ref_batch_stride, queue, ST_ ? win_stamp_buffer() : nullptr);      \
   } while (0)
+#define PCT_COL_B(L_, FU_, ST_)                                \
+  do {                                                         \
+    if (BLOCKV == 1024) PCT_COL_K(L_, FU_, 1024, ST_);         \
+    else if (BLOCKV == 512) PCT_COL_K(L_, FU_, 512, ST_);      \
+    else if (BLOCKV == 384) PCT_COL_K(L_, FU_, 384, ST_);      \
+    else PCT_COL_K(L_, FU_, 256, ST_);                         \
+  } while (0)
+#define PCT_COL(L_, FU_) PCT_COL_B(L_, FU_, false)
+  if (win_stamp_buffer() && L == 4) {   // diagnostic: per-phase cycle stamps (tools/stamp_msda.py)
+    if (ref) PCT_COL_B(4, true, true);
+    else PCT_COL_B(4, false, true);
+    return (int)hipGetLastError();
+  }
   if (ref) {
     if (L == 3) PCT_COL(3, true);
     else if (L == 4) PCT_COL(4, true);
@@ -508,6 +811,8 @@ int launch_msda_forward_col(const void *value, const int64_t *shapes, const int6
     else PCT_COL(5, false);
   }
 #undef PCT_COL
+#undef PCT_COL_B
+#undef PCT_COL_K
   return (int)hipGetLastError();
 }
 

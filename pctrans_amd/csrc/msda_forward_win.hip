@@ -575,6 +575,7 @@ unsigned *win_queue_slot(hipStream_t stream)
 
 static unsigned long long *g_stamp_buffer = nullptr;
 void set_win_stamp_buffer(void *p) { g_stamp_buffer = static_cast<unsigned long long *>(p); }
+unsigned long long *win_stamp_buffer() { return g_stamp_buffer; }
 
 // ---- launcher: returns -100 when this geometry is not covered (caller uses another kernel) ----------------------
 // ref == nullptr: plain op; ref != nullptr: fused front-end (loc = raw offsets, attn = raw logits).

@@ -89,8 +89,10 @@ def main():
                     torch.cuda.synchronize()
                     ms = e0.elapsed_time(e1) / args.iters
                     gbs = bytes_alg / (ms * 1e-3) / 1e9
-                    print("%s %-4s N=%-3d dist=%s  %8.3f ms  alg %7.1f MB  %8.1f GB/s  frac %.3f" % (
-                        sname, dn, N, dist, ms, bytes_alg / 1e6, gbs, gbs * 1e9 / PEAK), flush=True)
+                    from pctrans_amd import _lib
+                    kern = {0: "-", 1: "win", 2: "generic", 3: "dpp", 4: "col"}[_lib.lib().pct_msda_last_kernel()]
+                    print("%s %-4s N=%-3d dist=%s  %8.3f ms  alg %7.1f MB  %8.1f GB/s  frac %.3f  [%s]" % (
+                        sname, dn, N, dist, ms, bytes_alg / 1e6, gbs, gbs * 1e9 / PEAK, kern), flush=True)
                     del v, loc, a
 
 

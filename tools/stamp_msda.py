@@ -28,8 +28,14 @@ MSDA.ms_deform_attn_forward(v, sh, st, loc, w, 128)
 torch.cuda.synchronize()
 lib.pct_debug_set_stamp_buffer(None)
 t = buf.view(1024, 8).double().cpu()
-names = ["first prepass", "barrier A (boxes, pool free)", "windows", "staging issue", "barrier B (staged)", "gather+store",
-         "next item's prepass", "-"]
+kern = _lib.lib().pct_msda_last_kernel()
+if kern == 4:   # pyramid-column kernel
+    t = t[t.sum(1) > 0]
+    names = ["decode + record loads + boxes", "barrier A (boxes)", "windows + weight loads issued", "staging issue",
+             "staging barrier (DMA landed)", "gather (all phases)", "store + next item", "-"]
+else:
+    names = ["first prepass", "barrier A (boxes, pool free)", "windows", "staging issue", "barrier B (staged)", "gather+store",
+             "next item's prepass", "-"]
 tot = t.sum(1).mean().item()
 print("dist=%s N=%d  mean cycles per WG %.0f" % (dist, N, tot))
 for i, n in enumerate(names[:7]):
