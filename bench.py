@@ -54,6 +54,11 @@ def parse():
                     help="encoder feature levels: 4 = res2..res5 (north-star shape), 3 = res3..res5 (shipped yaml)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"],
                     help="autocast dtype of the transformer decoder; the pixel decoder is fp32 as in the reference")
+    ap.add_argument("--loc-dist", default="M", choices=["M", "I"],
+                    help="statistics of the encoder's sampling offsets (BASELINE.md 3 / SURVEY 8d): M = model-like, "
+                         "sampling_offsets.weight ~ N(0, s) scaled per layer so that offsets are N(0, 2 px) on the sampled "
+                         "level; I = the reference's initialisation (zero weight, head-directional bias of 1..4 px: what an "
+                         "untrained network gives)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -68,6 +73,43 @@ def build_head(args, device):
     torch.manual_seed(0)
     head = MaskFormerHead(**MaskFormerHead.from_config(cfg, shapes)).to(device).eval()
     return head, shapes
+
+
+def model_like_offsets(head, feats, sigma_px=2.0):
+    """Distribution M: give every encoder layer's sampling_offsets Linear a random weight and zero bias, then scale the
+    weight so that the offsets it produces on these features have standard deviation `sigma_px` (measured by running the
+    pixel decoder once with the layer's input captured).  Returns the realised per-layer standard deviations."""
+    import torch.nn.functional as F
+    layers = list(head.pixel_decoder.transformer.encoder.layers)
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    for lyr in layers:
+        so = lyr.self_attn.sampling_offsets
+        with torch.no_grad():
+            so.weight.copy_(torch.randn(so.weight.shape, generator=g).to(so.weight.device) * 0.1443)   # ~2 px on unit-variance rows
+            so.bias.zero_()
+    small = {k: v[:2] for k, v in feats.items()}
+    stds = []
+    for i, lyr in enumerate(layers):          # layer by layer: rescaling layer i changes what layers > i see
+        cap = {}
+        attn = lyr.self_attn
+        orig = attn.forward
+
+        def spy(query, *a, _orig=orig, _cap=cap, **kw):
+            qp = kw.get("_query_pos")
+            _cap["x"] = (query if qp is None else query + qp).detach()
+            return _orig(query, *a, **kw)
+        attn.forward = spy
+        try:
+            with torch.no_grad():
+                head.pixel_decoder.forward_features(small)
+        finally:
+            attn.forward = orig
+        off = F.linear(cap["x"].float(), attn.sampling_offsets.weight, attn.sampling_offsets.bias)
+        s = float(off.std())
+        with torch.no_grad():
+            attn.sampling_offsets.weight.mul_(sigma_px / s)
+        stds.append(float(F.linear(cap["x"].float(), attn.sampling_offsets.weight).std()))
+    return stds
 
 
 def synth_features(shapes, batch, image, device, seed):
@@ -112,7 +154,7 @@ def traffic_from_profile(args):
     `rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum` and `--pmc TCC_EA0_WRREQ_*` in separate passes around this very
     script, tools/pmc_bench_traffic.sh; bench.py cannot read counters itself).  Only reported when the committed
     measurement is for this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_msda_traffic_batch%d.json" % args.batch)
+    path = os.path.join(ROOT, "profiles", "r02_msda_traffic_batch%d_dist%s.json" % (args.batch, args.loc_dist))
     try:
         with open(path) as f:
             t = json.load(f)
@@ -177,6 +219,7 @@ def main():
 
     head, shapes = build_head(args, device)
     feats = synth_features(shapes, args.batch, args.image, device, seed=1234 + rank)
+    offset_std = model_like_offsets(head, feats) if args.loc_dist == "M" else None
     amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=(args.dtype == "bf16"))
 
     def step():
@@ -242,8 +285,13 @@ def main():
                 "queries": args.queries, "parallelism": "dp%d (images sharded, no data-path collective)" % world,
             },
             "roofline": {
-                "kernel": "pct::msda_forward_win_kernel<float,16,L,4,NS=4,fused> (MSDeformAttn forward incl. softmax + "
-                          "location math; windowed-LDS gather)",
+                "kernel": "pct::msda_forward_col_kernel<L,fused,256> (MSDeformAttn forward incl. softmax + location math; "
+                          "pyramid-column LDS gather, one lane per (query, head))",
+                "location_dist": ({"name": "M", "definition": "sampling_offsets.weight ~ N(0, s), zero bias, s scaled per "
+                                   "encoder layer so that offsets are N(0, 2 px) on the sampled level",
+                                   "offset_std_px_per_layer": offset_std} if args.loc_dist == "M" else
+                                  {"name": "I", "definition": "reference initialisation: zero sampling_offsets.weight, "
+                                   "head-directional bias of 1..4 px"}),
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic_from_profile(args),
                 "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_ms, "launches_timed": len(fwd),

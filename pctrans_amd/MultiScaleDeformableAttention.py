@@ -119,7 +119,7 @@ def fused_forward_supported(value, reference_points, sampling_offsets):
     """Geometry the fused front-end kernel covers (PCTrans: fp32, 16 channels per head, 4 or 8 points, 2-d refs)."""
     return (value.is_cuda and value.dtype == torch.float32 and value.dim() == 4 and value.shape[3] == 16
             and sampling_offsets.shape[4] in (4, 8) and reference_points.shape[-1] == 2
-            and value.numel() * 4 < 2 ** 31 - 1)
+            and value.shape[1] * value.shape[2] * value.shape[3] * 4 < 2 ** 31 - 1)      # per image; larger batches are chunked inside the library
 
 
 def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,

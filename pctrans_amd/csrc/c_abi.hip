@@ -66,6 +66,14 @@ int check_common(const void *value, const int64_t *shapes, const int64_t *starts
   return PCT_OK;
 }
 
+// largest number of images per launch whose value tensor stays below 2 GiB (at least 1)
+int images_per_launch(int N, long long image_bytes)
+{
+  int chunk = N;
+  while (chunk > 1 && (long long)chunk * image_bytes >= 0x7fffffffLL) chunk = (chunk + 1) / 2;
+  return chunk;
+}
+
 template <typename T, typename LT>
 int forward_impl(const void *value, const int64_t *shapes, const int64_t *starts, const LT *loc, const LT *attn,
                  int N, int S, int M, int D, int L, int Lq, int P, int im2col_step, void *out, void *stream)
@@ -76,8 +84,19 @@ int forward_impl(const void *value, const int64_t *shapes, const int64_t *starts
   if (N == 0 || Lq == 0) return PCT_OK;
   if (!out) return PCT_ERR_BAD_ARG;
   if ((uintptr_t)out % sizeof(typename pct::Traits<T>::store_t)) return PCT_ERR_ALIGNMENT;
-  return pct::launch_msda_forward<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out,
-                                     static_cast<hipStream_t>(stream));
+  // The specialised kernels address one launch's value tensor with 32-bit byte offsets: a batch whose value tensor
+  // reaches 2 GiB goes out in chunks of images, as the reference does with im2col_step (cu:66-80) -- same results.
+  using ST = typename pct::Traits<T>::store_t;
+  const int chunk = images_per_launch(N, (long long)S * M * D * (long long)sizeof(ST));
+  for (int b0 = 0; b0 < N; b0 += chunk) {
+    const int n = N - b0 < chunk ? N - b0 : chunk;
+    const int rc2 = pct::launch_msda_forward<T>(
+        static_cast<const ST *>(value) + (long long)b0 * S * M * D, shapes, starts, loc + (long long)b0 * Lq * M * L * P * 2,
+        attn + (long long)b0 * Lq * M * L * P, n, S, M, D, L, Lq, P, static_cast<ST *>(out) + (long long)b0 * Lq * M * D,
+        static_cast<hipStream_t>(stream));
+    if (rc2 != 0) return rc2;
+  }
+  return PCT_OK;
 }
 
 template <typename A>
@@ -169,11 +188,17 @@ int pct_ms_deform_attn_fused_forward_f32(const float *value, const int64_t *spat
   if (batch == 0 || num_query == 0) return PCT_OK;
   if (!output || !ref_points || ref_batch_stride < 0) return PCT_ERR_BAD_ARG;
   if (((uintptr_t)output | (uintptr_t)ref_points) & 3u) return PCT_ERR_ALIGNMENT;
-  const int r = pct::launch_msda_forward_special<float>(value, spatial_shapes, level_start, offsets, attn_logits, batch,
-                                                    spatial_size, num_heads, channels, num_levels, num_query,
-                                                    num_point, output, static_cast<hipStream_t>(stream), ref_points,
-                                                    ref_batch_stride);
-  return r == -100 ? PCT_ERR_UNSUPPORTED : r;
+  const long long S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query, P = num_point;
+  const int chunk = images_per_launch(batch, S * M * D * 4);               // as forward_impl: < 2 GiB of value per launch
+  for (int b0 = 0; b0 < batch; b0 += chunk) {
+    const int n = batch - b0 < chunk ? batch - b0 : chunk;
+    const int r = pct::launch_msda_forward_special<float>(
+        value + b0 * S * M * D, spatial_shapes, level_start, offsets + b0 * Lq * M * L * P * 2, attn_logits + b0 * Lq * M * L * P,
+        n, spatial_size, num_heads, channels, num_levels, num_query, num_point, output + b0 * Lq * M * D,
+        static_cast<hipStream_t>(stream), ref_points + b0 * ref_batch_stride, ref_batch_stride);
+    if (r != 0) return r == -100 ? PCT_ERR_UNSUPPORTED : r;
+  }
+  return PCT_OK;
 }
 
 int pct_ms_deform_attn_backward_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start,

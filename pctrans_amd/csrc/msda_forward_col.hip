@@ -769,9 +769,9 @@ int launch_msda_forward_col(const void *value, const int64_t *shapes, const int6
                                     return (v == 256 || v == 384 || v == 512 || v == 1024) ? v : 256; }();
   static const int pool_env = [] { const char *e = getenv("PCT_COL_POOL_KB"); return e ? atoi(e) : 0; }();
   const int BLOCKV = block_env;
-  const int wg_per_cu = BLOCKV == 1024 ? 1 : (BLOCKV == 256 ? 3 : 2);
-  const int pool_max = BLOCKV == 1024 ? 158 : (BLOCKV == 256 ? 52 : 78);
+  const int pool_max = BLOCKV == 1024 ? 158 : 78;
   const int pool_kb = (pool_env >= 16 && pool_env <= pool_max) ? pool_env : (BLOCKV == 1024 ? 150 : (BLOCKV == 256 ? 50 : 74));
+  const int wg_per_cu = BLOCKV == 1024 ? 1 : ((BLOCKV == 256 && pool_kb <= 52) ? 3 : 2);
   const int pool_px = pool_kb * 1024 / 64;
   const size_t lds = (size_t)pool_px * 64 + ((size_t)(BLOCKV / 64) * L * 2 + 4) * sizeof(unsigned);   // pool, boxes, queue words
   const dim3 grid(256 * wg_per_cu), block(BLOCKV);

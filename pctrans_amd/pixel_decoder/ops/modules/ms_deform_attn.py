@@ -84,7 +84,7 @@ class MSDeformAttn(nn.Module):
             return False
         return (value.dtype == torch.float32 and query.dtype == torch.float32 and reference_points.shape[-1] == 2
                 and self.d_model // self.n_heads == 16 and self.n_points in (4, 8) and self.n_heads <= 16
-                and value.numel() * 4 < 2 ** 31 - 1)
+                and value.shape[1] * value.shape[2] * value.shape[3] * 4 < 2 ** 31 - 1)   # per image: batches beyond 2 GiB are chunked in the library
 
     def forward_add_norm(self, query, reference_points, input_flatten, input_spatial_shapes,
                          input_level_start_index, input_padding_mask, residual, norm, query_pos=None):

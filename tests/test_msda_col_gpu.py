@@ -297,3 +297,37 @@ def test_module_on_device_matches_reference_module_golden(MSDA, golden, name, kw
     np.testing.assert_allclose(out2.detach().cpu().numpy(), g["out"], rtol=0, atol=1e-4)
     out2.square().sum().backward()
     assert torch.isfinite(m.value_proj.weight.grad).all() and float(m.value_proj.weight.grad.abs().max()) > 0
+
+
+# ---------------------------------------------------------------- batches whose value tensor passes 2 GiB
+def test_batch_256_is_chunked_inside_the_library_not_rerouted(MSDA, lib):
+    """N = 256 at the north-star shape: value is 2.85 GB, past the 32-bit byte offsets of one launch.  The C ABI sends it
+    out in chunks of images (as the reference does with im2col_step, cu:66-80) on the same kernel -- it used to drop to
+    the unfused path at a third of the speed.  Checked: same kernel, every image equal to what a 2-image call gives."""
+    sh = np.asarray(P2, dtype=np.int64)
+    S, L, P, M, D, N = n_px(P2), 4, 4, 8, 16, 256
+    g = torch.Generator(device="cuda").manual_seed(7)
+    shd, std = dev(sh), dev(starts_of(sh))
+    # two distinct images, repeated 128 times: the expected output is known from a 2-image call
+    v2 = torch.randn(2, S, M, D, device="cuda", generator=g)
+    off2 = torch.randn(2, S, M, L, P, 2, device="cuda", generator=g) * 2.0
+    lg2 = torch.randn(2, S, M, L * P, device="cuda", generator=g)
+    from msda_cases import pixel_centres
+    ref = torch.from_numpy(np.broadcast_to(pixel_centres(sh)[None, :, None, :], (1, S, L, 2)).astype(np.float32).copy()).cuda()
+    want2 = MSDA.ms_deform_attn_fused_forward(v2, shd, std, ref.expand(2, -1, -1, -1), off2, lg2)
+    v = v2.repeat(N // 2, 1, 1, 1)
+    off = off2.repeat(N // 2, 1, 1, 1, 1, 1)
+    lg = lg2.repeat(N // 2, 1, 1, 1)
+    assert v.numel() * 4 > 2 ** 31
+    lib.pct_msda_set_kernel_choice(-1)
+    got = MSDA.ms_deform_attn_fused_forward(v, shd, std, ref.expand(N, -1, -1, -1), off, lg)
+    assert lib.pct_msda_last_kernel() == K_COL
+    assert float((got.view(N // 2, 2, S, M * D) - want2[None]).abs().max()) <= 1e-5
+    # the plain op too
+    norm = torch.stack([shd[:, 1], shd[:, 0]], -1).float()
+    loc2 = (ref[:, :, None, :, None, :] + off2 / norm[None, None, None, :, None, :]).contiguous()
+    w2 = torch.softmax(lg2, -1).view(2, S, M, L, P).contiguous()
+    want2p = MSDA.ms_deform_attn_forward(v2, shd, std, loc2, w2, 64)
+    del off, lg
+    gotp = MSDA.ms_deform_attn_forward(v, shd, std, loc2.repeat(N // 2, 1, 1, 1, 1, 1), w2.repeat(N // 2, 1, 1, 1, 1), 128)
+    assert float((gotp.view(N // 2, 2, S, M * D) - want2p[None]).abs().max()) <= 1e-5
