@@ -539,36 +539,47 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
 }
 
 // One set of 8 per-XCD item counters per launch, from a small per-device ring zeroed once at allocation (the kernel
-// leaves every counter at zero again, see its item loop).  Launches on one stream are ordered; 256 launches may be in
-// flight across streams before a set is reused.  Returns nullptr (static item stride) when the ring cannot be
+// leaves every counter at zero again, see its item loop).  Launches on one stream are ordered; 256 eager launches may
+// be in flight across streams before a set is reused.  Returns nullptr (static item stride) when the ring cannot be
 // allocated -- e.g. the very first launch of the process happening under stream capture -- or with PCT_WIN_QUEUE=0.
 unsigned *win_queue_slot(hipStream_t stream)
 {
   static const bool enabled = [] { const char *e = getenv("PCT_WIN_QUEUE"); return !(e && e[0] == '0'); }();
   if (!enabled) return nullptr;
-  constexpr int MAX_DEV = 64, RING = 256;
+  // RING sets cycle through the eager launches; CAPTURE_POOL sets are handed out ONCE each to launches recorded into a
+  // HIP graph (a graph bakes the pointer in: its set must never be shared with an eager launch that could run at the
+  // same time on another stream -- two launches on one set would skip / repeat items and leave the counters non-zero).
+  // When the pool is exhausted a captured launch falls back to the static item stride.
+  constexpr int MAX_DEV = 64, RING = 256, CAPTURE_POOL = 4096;
   static std::mutex mu;
   static unsigned *ring[MAX_DEV] = {};
   static unsigned seq[MAX_DEV] = {};
+  static unsigned cap_used[MAX_DEV] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  const bool capturing = cap != hipStreamCaptureStatusNone;
   std::lock_guard<std::mutex> lock(mu);
   if (!ring[dev]) {
     // never allocate under stream capture (an allocation would invalidate the capture): static stride for this launch
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
+    if (capturing) return nullptr;
     void *p = nullptr;
+    const size_t bytes = (size_t)(RING + CAPTURE_POOL) * 8 * sizeof(unsigned);
     // (the memset runs on the null stream; launches may come from non-blocking streams: wait for it once)
-    if (hipMalloc(&p, RING * 8 * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, RING * 8 * sizeof(unsigned)) != hipSuccess ||
-        hipDeviceSynchronize() != hipSuccess) {
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
       (void)hipGetLastError();
       if (p) (void)hipFree(p);
       return nullptr;
     }
     ring[dev] = static_cast<unsigned *>(p);
+  }
+  if (capturing) {
+    if (cap_used[dev] >= (unsigned)CAPTURE_POOL) return nullptr;
+    return ring[dev] + 8 * (size_t)(RING + cap_used[dev]++);
   }
   return ring[dev] + 8 * (seq[dev]++ % RING);
 }

@@ -92,6 +92,49 @@ def linear_k128(x, weight, bias=None, relu=False, x_add=None):
     return out.view(*x.shape[:-1], n)
 
 
+_PAD32 = {}                                      # id(conv) -> (weight version, bias version, w32, b32)
+
+
+def conv1x1_from_token_rows_supported(x, conv):
+    """A 1x1 convolution of 128 channels-last feature maps with at most 32 output channels, forward only, small batch:
+    the decoder's `mask_head` (dec.py:539) on the pixel decoder's finest map, which is a transposed VIEW of the encoder's
+    [N, S, 128] token rows."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 128 and x.shape[0] <= 4):
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+        return False
+    H, W = x.shape[2], x.shape[3]
+    return (x.stride(1) == 1 and x.stride(3) == 128 and x.stride(2) == 128 * W and H * W >= 4096
+            and x.data_ptr() % 16 == 0 and (x.stride(0) * 4) % 16 == 0
+            and conv.kernel_size == (1, 1) and conv.in_channels == 128 and conv.out_channels <= 32
+            and conv.weight.dtype == torch.float32 and getattr(conv, "norm", None) is None
+            and getattr(conv, "activation", None) is None)
+
+
+def conv1x1_from_token_rows(x, conv):
+    """-> conv(x) as fp32 [N, Cout, H, W], each image's H*W token rows through the K = 128 MFMA kernel (weights padded to 32
+    output channels).  Deterministic run to run, unlike the library's batched bf16 GEMM this replaces at batch 1-4
+    (tools/diag_determinism.py), which is what lets a HIP-graph replay of the head reproduce the eager forward bit for
+    bit; fp32-accurate where autocast would have rounded the operands to bf16."""
+    N, _, H, W = x.shape
+    co = conv.out_channels
+    key = id(conv)
+    bv = conv.bias._version if conv.bias is not None else -1
+    ent = _PAD32.get(key)
+    if ent is None or ent[0] != conv.weight._version or ent[1] != bv or ent[2].device != x.device:
+        w32 = torch.zeros((32, 128), dtype=torch.float32, device=x.device)
+        w32[:co] = conv.weight.detach().reshape(co, 128)
+        b32 = torch.zeros((32,), dtype=torch.float32, device=x.device)
+        if conv.bias is not None:
+            b32[:co] = conv.bias.detach()
+        if len(_PAD32) > 64:
+            _PAD32.clear()
+        ent = _PAD32[key] = (conv.weight._version, bv, w32, b32)
+    outs = [linear_k128(x[n].permute(1, 2, 0).reshape(H * W, 128), ent[2], ent[3]) for n in range(N)]   # views: no copy
+    y = torch.stack(outs, 0)                                               # [N, HW, 32]
+    return y[..., :co].permute(0, 2, 1).reshape(N, co, H, W).contiguous()
+
+
 def linear_k128_multi(x, layers, x_add=None):
     """[lin(x + x_add if use_add else x) for (lin, use_add) in layers] in ONE launch of the K = 128 kernel: the rows are
     read from HBM once for all layers (MSDeformAttn: value_proj(src), sampling_offsets(src + pos),

@@ -398,10 +398,15 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         mf_lp = _lp(mask_features)                 # one autocast cast shared by the semantic head and the mask head
         if self.sem_loss_on:
             sem_logits_pred = self.logits(self.seg_head(mf_lp))
-        mask_feat = self.mask_head(mf_lp)
-        # the fused mask-head kernels read fp32 features: convert once, not once per prediction head
         feats_f32 = None
-        if mask_feat.is_cuda and mask_feat.dtype != torch.float32 and not (
+        if fused_ops.conv1x1_from_token_rows_supported(mask_features, self.mask_head):
+            # small batches: the 16-channel projection on the deterministic K = 128 kernel, straight from the encoder's
+            # token rows (a HIP-graph replay of the head then reproduces the eager forward bit for bit)
+            mask_feat = feats_f32 = fused_ops.conv1x1_from_token_rows(mask_features, self.mask_head)
+        else:
+            mask_feat = self.mask_head(mf_lp)
+        # the fused mask-head kernels read fp32 features: convert once, not once per prediction head
+        if feats_f32 is None and mask_feat.is_cuda and mask_feat.dtype != torch.float32 and not (
                 torch.is_grad_enabled() and mask_feat.requires_grad):
             feats_f32 = mask_feat.float().contiguous()
 

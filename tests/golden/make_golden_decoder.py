@@ -23,6 +23,13 @@ them) run on the reference's own MSDeformAttn module and transformer.py helpers,
 
     MSDeformAttnTransformerEncoderOnly :23-89   ...EncoderLayer :92-131   ...Encoder :134-162
 
+`MSDeformAttnPixelDecoder.forward_features` (pixel_decoder/msdeformattn.py:314-360) is a method whose body touches only torch
+`nn` modules once the encoder uses all four feature levels (num_fpn_levels == 0, :257-258: no detectron2 Conv2d / get_norm
+is reached): it is taken from the AST and run on a parameter bag holding exactly what the reference constructor builds for
+that case (:213-226 `nn.Sequential(nn.Conv2d, nn.GroupNorm(32, conv_dim))` per level, the reference encoder class, the
+reference PositionEmbeddingSine), and `MaskFormerHead.forward / layers` (meta_arch/mask_former_head.py:117-154) on a bag
+holding that pixel decoder and the reference transformer decoder.
+
 Finally the whole `MultiScaleMaskedTransformerDecoder` (:267-768) is run in eval mode (targets=None) for a configuration
 that never touches its detectron2 names (in_channels == hidden_dim, no forced input projection, no semantic head): the
 class is taken from the AST with the `@configurable` decorator of `__init__` (it only adds the from_config calling
@@ -142,6 +149,27 @@ def load_reference_encoder(ref_root):
           "uniform_": uniform_, "normal_": normal_}
     exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
     return ns["MSDeformAttnTransformerEncoderOnly"]
+
+
+def load_reference_pixel_decoder_methods(ref_root):
+    """forward_features of MSDeformAttnPixelDecoder and forward / layers of MaskFormerHead, as plain functions."""
+    from torch.cuda.amp import autocast
+    out = {}
+    for rel, cls, names in (("connectomics/model/maskformer_block/pixel_decoder/msdeformattn.py", "MSDeformAttnPixelDecoder",
+                             {"forward_features"}),
+                            ("connectomics/model/maskformer_block/meta_arch/mask_former_head.py", "MaskFormerHead",
+                             {"forward", "layers"})):
+        path = os.path.join(ref_root, rel)
+        tree = ast.parse(open(path).read(), filename=path)
+        picked = []
+        for node in tree.body:
+            if isinstance(node, ast.ClassDef) and node.name == cls:
+                picked = [n for n in node.body if isinstance(n, ast.FunctionDef) and n.name in names]
+        assert len(picked) == len(names), (cls, names)
+        ns = {"torch": torch, "nn": nn, "F": F, "np": np, "autocast": autocast}
+        exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+        out.update({cls + "." + k: ns[k] for k in names})
+    return out
 
 
 def load_reference_postprocessing(ref_root):
@@ -329,6 +357,69 @@ def main():
     for i, a in enumerate(out["aux_reference_points"]):
         arrays["aux%d_reference_points" % i] = a["reference_points"]
     save("dec_full_decoder", **arrays)
+
+    # ---- pixel decoder glue (input projections + GroupNorm, sine PE, encoder, split per level) and the head ------------
+    # 4 encoder levels (the north-star geometry) => num_fpn_levels == 0; conv_dim 128 / 8 heads as configured.
+    import importlib.util
+    meth = load_reference_pixel_decoder_methods(args.ref)
+    spec = importlib.util.spec_from_file_location(
+        "ref_position_encoding3", os.path.join(args.ref, os.path.dirname(DEC), "position_encoding.py"))
+    pe_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pe_mod)
+    from golden_params import fill_pixel_decoder
+    conv_dim, chans = 128, {"res2": 16, "res3": 24, "res4": 32, "res5": 40}
+    feat_hw = {"res2": (16, 20), "res3": (8, 10), "res4": (4, 5), "res5": (2, 3)}
+
+    class PixelDecoderBag(nn.Module):       # the attributes the reference constructor sets for this case (:197-258)
+        def __init__(self):
+            super().__init__()
+            self.in_features = ["res2", "res3", "res4", "res5"]
+            self.transformer_in_features = ["res2", "res3", "res4", "res5"]
+            self.transformer_num_feature_levels = 4
+            self.input_proj = nn.ModuleList(
+                nn.Sequential(nn.Conv2d(chans[f], conv_dim, kernel_size=1), nn.GroupNorm(32, conv_dim))
+                for f in self.transformer_in_features[::-1])
+            self.transformer = RefEncoder(d_model=conv_dim, dropout=0.0, nhead=8, dim_feedforward=1024,
+                                          num_encoder_layers=2, num_feature_levels=4)
+            self.pe_layer = pe_mod.PositionEmbeddingSine(conv_dim // 2, normalize=True)
+            self.maskformer_num_feature_levels = 3
+            self.num_fpn_levels = 0
+            self.lateral_convs, self.output_convs = [], []
+    PixelDecoderBag.forward_features = meth["MSDeformAttnPixelDecoder.forward_features"]
+    pix = PixelDecoderBag().eval()
+    fill_pixel_decoder(pix, 51)
+    g2 = torch.Generator().manual_seed(2025)      # (its own stream: the fixtures below keep the values they always had)
+    feats = {f: torch.randn(2, chans[f], *feat_hw[f], generator=g2) for f in chans}
+    with torch.no_grad():
+        mask_features, enc_feat, multi = pix.forward_features(feats)
+    arrays = {"feat_" + f: v for f, v in feats.items()}
+    arrays.update(mask_features=mask_features, transformer_encoder_features=enc_feat,
+                  param_names=np.asarray(sorted(pix.state_dict())))
+    for i, m_ in enumerate(multi):
+        arrays["multi_scale_%d" % i] = m_
+    save("dec_pixel_decoder_l4", **arrays)
+
+    class HeadBag(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.pixel_decoder = pix
+            self.predictor = ref.MultiScaleMaskedTransformerDecoder(
+                128, True, hidden_dim=128, num_queries=6, nheads=8, dim_feedforward=256, dec_layers=3, pre_norm=False,
+                mask_dim=16, enforce_input_project=False, points_num=1, sem_loss_on=False, norm="GN", rel_coord=True)
+            self.transformer_in_feature = "multi_scale_pixel_decoder"
+            self.attn_mask_threshold = 0.5
+    HeadBag.forward = meth["MaskFormerHead.forward"]
+    HeadBag.layers = meth["MaskFormerHead.layers"]
+    head = HeadBag().eval()
+    deterministic_fill(head.predictor, 41)
+    with torch.no_grad():
+        pred, mf = head(feats)
+    arrays = {"feat_" + f: v for f, v in feats.items()}
+    arrays.update(pred_masks=pred["pred_masks"], reference_points=pred["reference_points"], mask_features=mf,
+                  n_aux=len(pred["aux_outputs"]))
+    for i, a in enumerate(pred["aux_outputs"]):
+        arrays["aux%d_pred_masks" % i] = a["pred_masks"]
+    save("dec_head_l4", **arrays)
 
     # ---- instance post-processing helpers (arch/maskformer.py) -------------------------------------------------------
     post = load_reference_postprocessing(args.ref)

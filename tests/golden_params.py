@@ -24,3 +24,15 @@ def deterministic_fill(module, seed):
                 x = 0.05 * x
             p.copy_(torch.from_numpy(x.astype(np.float32)))
     return module
+
+
+def fill_pixel_decoder(module, seed):
+    """deterministic_fill + GroupNorm scales of the input projections around 1 (their names carry no "norm"; left at
+    0.05 N they would flatten the encoder's input)."""
+    deterministic_fill(module, seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if name.startswith("input_proj.") and name.endswith(".1.weight"):
+                rs = np.random.RandomState((zlib.crc32(name.encode()) + seed + 7) % (2 ** 31))
+                p.copy_(torch.from_numpy((1.0 + 0.2 * rs.standard_normal(tuple(p.shape))).astype(np.float32)))
+    return module

@@ -149,25 +149,85 @@ def test_head_forward_is_bitwise_repeatable_at_bench_geometry():
                 assert torch.equal(a["pred_masks"], b["pred_masks"])
 
 
-def test_graphed_forward_replays_the_head_bit_identically():
+@pytest.mark.parametrize("batch", [1, 2])
+def test_graphed_forward_replays_the_head_bit_identically(batch):
     """Every kernel launches on the current stream without host synchronisation, so the forward-only head is
-    capturable in a HIP graph.  Replay on fresh inputs must reproduce the eager forward: bit for bit through the pixel
-    decoder (this package's kernels + fp32 convolutions), and to bf16 rounding in the mask logits -- at batch 1-2 the
-    libraries are not run-to-run deterministic themselves (measured: hipBLASLt's batched bf16 GEMM behind the 16-channel
-    1x1 `mask_head` projection and MIOpen's bf16 3x3 convolutions return results that differ by one bf16 ulp between two
-    eager calls on the same input), which is where the one-ulp differences come from."""
+    capturable in a HIP graph.  Replay on fresh inputs must reproduce the eager forward BIT FOR BIT: mask features, mask
+    logits of every prediction head and reference points.  (Round 1 had to allow bf16 rounding here: at batch 1-2 the
+    library's batched bf16 GEMM behind the 16-channel `mask_head` projection is not run-to-run deterministic --
+    tools/diag_determinism.py, test_two_eager_forwards_are_bitwise_equal_module_by_module; that projection now runs on
+    this package's K = 128 kernel at small batch.  The semantic head's MIOpen convolutions still are not, but nothing
+    else reads their output.)"""
     from pctrans_amd.graph import GraphedForward
     head, shapes = _head(4, Q=20)
-    feats = _feats(shapes, 1, 256, 256, seed=5)
+    feats = _feats(shapes, batch, 256, 256, seed=5)
     fwd = GraphedForward(head, feats, autocast_dtype=torch.bfloat16)
-    other = _feats(shapes, 1, 256, 256, seed=6)
-    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-        want, want_mf = head(other)
-    got, got_mf = fwd(other)
-    d_mf = float((got_mf.float() - want_mf.float()).abs().max())
-    assert d_mf == 0.0, "replay != eager in the pixel decoder: max |d mask_features| = %g" % d_mf
-    w, g = want["pred_masks"].float(), got["pred_masks"].float()
-    tol = 2.0 ** -6 * float(w.abs().max())                      # a few bf16 ulps of the largest logit
-    d_mask = float((g - w).abs().max())
-    assert d_mask <= tol, "replay vs eager: max |d pred_masks| = %g > %g" % (d_mask, tol)
-    assert float(((g - w).abs() > 0).float().mean()) < 0.05     # and only isolated elements differ at all
+    for seed in (6, 7):
+        other = _feats(shapes, batch, 256, 256, seed=seed)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            want, want_mf = head(other)
+        got, got_mf = fwd(other)
+        assert torch.equal(got_mf, want_mf), "replay != eager in the pixel decoder"
+        assert torch.equal(got["pred_masks"], want["pred_masks"])
+        assert torch.equal(got["reference_points"], want["reference_points"])
+        for a, b in zip(got["aux_outputs"], want["aux_outputs"]):
+            assert torch.equal(a["pred_masks"], b["pred_masks"])
+        if "sem_mask" in want:                                   # MIOpen's bf16 3x3 convolutions: bf16 rounding allowed
+            w = want["sem_mask"].float()
+            assert float((got["sem_mask"].float() - w).abs().max()) <= 2.0 ** -6 * max(1.0, float(w.abs().max()))
+
+
+def _record_all_modules(head, feats, dtype):
+    """Run the head once, return {module name: [output tensors, flattened]} for EVERY sub-module (leaf or not)."""
+    rec, hooks = {}, []
+
+    def flat(o):
+        if torch.is_tensor(o):
+            return [o.detach().clone()]
+        if isinstance(o, (list, tuple)):
+            return [t for x in o for t in flat(x)]
+        if isinstance(o, dict):
+            return [t for k in sorted(o) for t in flat(o[k])]
+        return []
+
+    def mk(name):
+        def hook(_m, _i, out):
+            rec.setdefault(name, []).extend(flat(out))
+        return hook
+    for name, m in head.named_modules():
+        hooks.append(m.register_forward_hook(mk(name or "<head>")))
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=dtype, enabled=dtype is not None):
+            head(feats)
+    finally:
+        for h in hooks:
+            h.remove()
+    return rec
+
+
+def test_two_eager_forwards_are_bitwise_equal_module_by_module():
+    """The geometry at which a graph replay once differed from the eager forward (batch 1, 256^2, 20 queries, bf16
+    autocast): two EAGER forwards on the same input, every sub-module's output compared bit for bit.  Any difference is a
+    run-to-run non-determinism of whatever that module launches -- for this package's kernels that would be a missing
+    wait or barrier, and is not tolerated; the library calls that were blamed in round 1 (hipBLASLt's batched bf16 GEMM
+    behind the 1x1 `mask_head` projection, MIOpen's bf16 3x3 convolutions of `seg_head`) are the only modules allowed to
+    differ, and then only by bf16 rounding."""
+    head, shapes = _head(4, Q=20)
+    feats = _feats(shapes, 1, 256, 256, seed=5)
+    a = _record_all_modules(head, feats, torch.bfloat16)
+    b = _record_all_modules(head, feats, torch.bfloat16)
+    assert a.keys() == b.keys() and len(a) > 100
+    differing = []
+    for name in a:
+        assert len(a[name]) == len(b[name]), name
+        if any(not torch.equal(x, y) for x, y in zip(a[name], b[name])):
+            differing.append(name)
+    library_ops = ("predictor.mask_head", "predictor.seg_head", "predictor.logits")
+    # a module that only CONSUMES a library op's output inherits its difference: the decoder and the head themselves
+    downstream = ("predictor", "<head>")
+    culprits = [n for n in differing if not n.startswith(library_ops) and n not in downstream]
+    assert not culprits, "not run-to-run deterministic: %s (all differing: %s)" % (culprits, differing)
+    for name in differing:
+        for x, y in zip(a[name], b[name]):
+            d = float((x.float() - y.float()).abs().max())
+            assert d <= 2.0 ** -6 * max(1.0, float(x.float().abs().max())), (name, d)
