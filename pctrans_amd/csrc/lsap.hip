@@ -37,11 +37,29 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float *__restrict__ cost
   __shared__ unsigned char scanned_t[LSAP_MAXG];  // SR
 
   const int b = blockIdx.x, lane = threadIdx.x;
-  const int g = G[b];
+  const int g = G[b];                             // device data: validated here, not trusted
   const float *C = cost + (size_t)b * Q * ldg;
   int *out = row_for_target + (size_t)b * ldg;
   for (int j = lane; j < ldg; j += 64) out[j] = -1;
   if (g <= 0) return;
+  if (g > ldg || g > Q || g > LSAP_MAXG) {        // more targets than columns / queries: no assignment exists
+    if (lane == 0) status[b] = 1;
+    return;
+  }
+  // scipy raises on any NaN or -inf entry ("matrix contains invalid numeric entries"): report those the same way
+  // (+inf entries are allowed: an infeasible problem is detected by the search below)
+  {
+    int bad = 0;
+    for (int j = lane; j < Q; j += 64)
+      for (int i = 0; i < g; ++i) {
+        const float c = C[(size_t)j * ldg + i];
+        bad |= (c != c) || (c == -INFINITY);
+      }
+    if (__any(bad)) {
+      if (lane == 0) status[b] = 1;
+      return;
+    }
+  }
   for (int j = lane; j < Q; j += 64) {
     v[j] = 0.0;
     tgt_of_query[j] = -1;

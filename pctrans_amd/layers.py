@@ -113,9 +113,14 @@ class CachedLinear(nn.Linear):
     low-precision copies of weight and bias instead of re-casting them on every forward (autocast's own cache lives only
     for one autocast region: ~330 cast launches per decoder forward), and can apply ReLU in the GEMM epilogue.  The copies
     are keyed on the parameters' version counters and storage, so optimizer steps, `load_state_dict` and `.to()` refresh
-    them.  Anything else (fp32, CPU, autograd) is plain `nn.Linear`."""
+    them.  Writes through `.data` (e.g. an EMA swap `p.data.copy_(...)`) do NOT bump the version counter: call
+    `invalidate()` after such a write.  Anything else (fp32, CPU, autograd) is plain `nn.Linear`."""
 
     _lp_cache = None
+
+    def invalidate(self):
+        """Drop the cached low-precision copies (after a write the version counters cannot see)."""
+        self._lp_cache = None
 
     def _low_precision(self, dtype):
         w, b = self.weight, self.bias

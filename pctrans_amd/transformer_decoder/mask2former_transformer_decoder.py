@@ -140,7 +140,10 @@ class CrossAttentionLayer(nn.Module):
         k = self.ca_kcontent_proj(memory)
         k_pos = self.ca_kpos_proj(pos)
         fused = (memory_key_padding_mask is None and k.is_cuda and k.dtype == torch.bfloat16
-                 and not (torch.is_grad_enabled() and (tgt.requires_grad or memory.requires_grad))
+                 and not (torch.is_grad_enabled() and (
+                     tgt.requires_grad or memory.requires_grad or q.requires_grad or k.requires_grad
+                     or k_pos.requires_grad or self.ca_v_proj.weight.requires_grad
+                     or self.ca_qpos_sine_proj.weight.requires_grad or self.ca_qpos_proj.weight.requires_grad))
                  and C // h == 16 and self.cross_attn.dropout == 0.0
                  and (memory_mask is None or (memory_mask.dtype == torch.bool
                                               and tuple(memory_mask.shape) == (bs, 1, Q, hw))))

@@ -458,3 +458,89 @@ def test_matcher_on_device_equals_the_scipy_path():
     for (i, j), (ih, jh) in zip(on_dev, on_host):
         assert i.is_cuda and i.dtype == torch.int64
         assert torch.equal(i.cpu(), ih) and torch.equal(j.cpu(), jh)
+
+
+def test_device_lsap_flags_what_scipy_rejects():
+    """scipy.optimize.linear_sum_assignment raises on a NaN or -inf entry anywhere in the matrix and on more columns than
+    rows in the transposed call the reference makes (matcher.py:154-165); the device solver reports those problems
+    through status instead of returning an assignment (and never indexes past its LDS state)."""
+    cost = torch.randn(4, 12, 6).cuda()
+    cost[1, 3, 2] = float("nan")                 # one NaN among valid entries
+    cost[2, 0, 5] = float("-inf")
+    cost[3, :, 1] = float("inf")                 # a target nobody can take: infeasible, as before
+    rows, status = fused_ops.lsap(cost, torch.tensor([6, 6, 6, 6], dtype=torch.int32))
+    assert status.cpu().tolist() == [0, 1, 1, 1]
+    assert (rows[0] >= 0).all() and len(set(rows[0].cpu().tolist())) == 6
+    # NaN / -inf in columns past num_target are not part of the problem
+    cost2 = torch.randn(1, 12, 6).cuda()
+    cost2[0, :, 4:] = float("nan")
+    rows2, status2 = fused_ops.lsap(cost2, torch.tensor([4], dtype=torch.int32))
+    assert int(status2[0]) == 0 and (rows2[0, :4] >= 0).all() and (rows2[0, 4:] == -1).all()
+    # more targets than queries, more targets than columns: flagged, nothing written out of bounds
+    _, status3 = fused_ops.lsap(torch.randn(2, 5, 8).cuda(), torch.tensor([6, 9], dtype=torch.int32))
+    assert status3.cpu().tolist() == [1, 1]
+
+
+def test_cross_attention_trains_its_projections_when_the_inputs_are_detached():
+    """bf16 autocast, grad enabled, trainable ca_* weights but detached inputs (a frozen pixel decoder / query
+    embedding): the layer must take the differentiable path -- the forward-only MFMA attention kernel would leave the
+    projections without gradients, silently."""
+    from pctrans_amd.transformer_decoder.mask2former_transformer_decoder import CrossAttentionLayer
+    torch.manual_seed(0)
+    ca = CrossAttentionLayer(128, 8).cuda()
+    Q, N, HW = 10, 2, 64
+    tgt, mem, pos = torch.randn(Q, N, 128).cuda(), torch.randn(HW, N, 128).cuda(), torch.randn(HW, N, 128).cuda()
+    qpos, qsine = torch.randn(Q, N, 128).cuda(), torch.randn(Q, N, 256).cuda()
+    mask = torch.zeros(N, 1, Q, HW, dtype=torch.bool).cuda()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = ca(tgt, mem, memory_mask=mask, pos=pos, query_pos=qpos, query_sine_embed=qsine, is_first=True)
+    out.float().square().mean().backward()
+    for name in ("ca_qcontent_proj", "ca_kcontent_proj", "ca_kpos_proj", "ca_v_proj", "ca_qpos_sine_proj", "ca_qpos_proj"):
+        g = getattr(ca, name).weight.grad
+        assert g is not None and float(g.abs().max()) > 0, name
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):          # and forward-only still fuses
+        out2 = ca(tgt, mem, memory_mask=mask, pos=pos, query_pos=qpos, query_sine_embed=qsine, is_first=True)
+    assert float((out2.float() - out.float()).abs().max()) < 0.1
+
+
+def test_loss_and_postprocessing_definitions_on_the_device(golden):
+    """SURVEY 8 f-3 / f-4 on device tensors: dice_loss, sigmoid_ce_loss, calculate_uncertainty
+    (maskformer_criterion.py:23-115), batch_dice_loss, batch_sigmoid_ce_loss (matcher.py:15-62), dice_for, mask_post,
+    comput_mmi (arch/maskformer.py:349-431) against the vectors the reference's own functions produced."""
+    import numpy as np
+    from pctrans_amd.arch import maskformer as mfm
+    from pctrans_amd.loss import maskformer_criterion as crit
+    from pctrans_amd.loss import matcher
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    g = golden("loss_functions")
+    logits, tgt, tgt2, nm = t(g["logits"]), t(g["targets"]), t(g["targets2"]), float(g["num_masks"])
+    np.testing.assert_allclose(crit.dice_loss(logits, tgt, nm).cpu().numpy(), g["dice_loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(crit.sigmoid_ce_loss(logits, tgt, nm).cpu().numpy(), g["sigmoid_ce_loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(crit.calculate_uncertainty(logits[:, None, :]).cpu().numpy(), g["uncertainty"], rtol=0, atol=0)
+    np.testing.assert_allclose(matcher.batch_dice_loss(logits, tgt2).cpu().numpy(), g["batch_dice"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(matcher.batch_sigmoid_ce_loss(logits, tgt2).cpu().numpy(), g["batch_ce"], rtol=1e-5, atol=2e-5)
+    g = golden("arch_mask_post")
+    inst = t(g["inst_masks"])
+    np.testing.assert_allclose(mfm.dice_for(inst).cpu().numpy(), g["dice"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mfm.mask_post(inst, thres1=0.5, thres2=0.6, bd_flag=False).cpu().numpy(), g["post_soft"],
+                               rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(mfm.mask_post(inst, thres1=0.5, thres2=0.6, bd_flag=True).cpu().numpy(), g["post_hard"])
+    np.testing.assert_allclose(mfm.mask_post(inst, thres1=0.15, thres2=0.25).cpu().numpy(), g["post_bbbc"], rtol=0, atol=1e-6)
+    for (a, b, c), want in zip(g["mmi_in"], g["mmi_out"]):
+        got = float(mfm.comput_mmi(torch.tensor(float(a)).cuda(), torch.tensor(float(b)).cuda(), torch.tensor(float(c)).cuda()))
+        assert abs(got - float(want)) <= 1e-6 * max(1.0, abs(float(want)))
+    g = golden("dec_query_contrast")            # query-contrast selection (dec.py:800-900) on device tensors
+    from pctrans_amd.transformer_decoder import query_contrast as qc
+    pos_indices = [(t(g["pos_src_%d" % b]), t(g["pos_tgt_%d" % b])) for b in range(2)]
+    items_q = qc.select_pos_neg_query(t(g["query"]), t(g["emb_dist"]), pos_indices)
+    items_m = qc.select_pos_neg_mask(t(g["masks"]), t(g["emb_dist"]), pos_indices)
+    assert len(items_q) == int(g["n_items_q"]) and len(items_m) == int(g["n_items_m"])
+    # (negatives come in set-iteration order in the reference, ascending here: compared per group up to order, as the loss --
+    # a logsumexp over each group -- does; see tests/test_decoder_golden.py)
+    for prefix, items in (("q", items_q), ("m", items_m)):
+        for i, it in enumerate(items):
+            want_c, want_l = g["%s%d_contrast" % (prefix, i)].ravel(), g["%s%d_label" % (prefix, i)]
+            got_c, got_l = it["contrast"].cpu().numpy().ravel(), it["label"].cpu().numpy()
+            np.testing.assert_array_equal(got_l, want_l)
+            for lab in (0, 1):
+                np.testing.assert_allclose(np.sort(got_c[got_l == lab]), np.sort(want_c[want_l == lab]), rtol=1e-5, atol=1e-5)
