@@ -118,35 +118,121 @@ def synth_features(shapes, batch, image, device, seed):
             for k, s in shapes.items()}
 
 
+def host_cpu():
+    """(model name, physical cores, logical CPUs) of this host, from /proc/cpuinfo."""
+    model, cores, logical = "unknown", set(), 0
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("processor"):
+                    logical += 1
+                elif line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                    cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or logical or 1), (logical or 1)
+
+
 def cpu_baseline(args, levels_hw):
-    """Oracle MSDeformAttn forward (one encoder layer, one image) on the host cores, bounded in time."""
+    """The CPU side of the comparison, rank 0 / N = 1 only, bounded to ~25 s in all:
+      * headline: the C/OpenMP oracle's MSDeformAttn forward (one encoder layer, one image of the bench geometry,
+        model-like locations) on all PHYSICAL cores, plus the same on 1 thread;
+      * table: P1 / P2 / P4 x {U, M} (SURVEY 8d) on all physical cores, ~1 s each;
+      * head: BASELINE.json configs[0] -- the whole head (pixel decoder + transformer decoder) on a 256 x 256 tile,
+        ResNet-18 channels, 50 queries, batch 1, on the CPU through the dense PyTorch formulation of the op (what the
+        reference falls back to when ops/ is not built, ops/modules/ms_deform_attn.py:119-121)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from msda_cases import make_case
     from oracle import msda_oracle as orc
+    model, phys, logical = host_cpu()
+    threads_max = orc.max_threads()
+    threads = max(1, min(phys, threads_max))
+
+    def timed(case, seconds, nthreads, warm_seconds=0.0):
+        orc.set_threads(nthreads)
+        a = (case["value"], case["shapes"], case["starts"], case["loc"], case["attn"])
+        orc.forward(*a)                                                         # warm-up
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < warm_seconds:      # (the first second of a fresh OpenMP team runs ~8x slower)
+            orc.forward(*a)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            orc.forward(*a)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or reps >= 20000:
+                return reps, el
+
+    def alg_bytes(shapes, P=4):
+        S_ = sum(h * w for h, w in shapes)
+        return S_ * (2 * 128 * 4 + 3 * 8 * len(shapes) * P * 4)
+
     S = sum(h * w for h, w in levels_hw)
     c = make_case(seed=0, N=1, M=8, D=16, Lq=S, P=4, shapes=levels_hw, model_like=True)
-    threads = orc.max_threads()
-    orc.forward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"])      # warm-up
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        orc.forward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"])
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= args.cpu_seconds or reps >= 20000:
-            break
-    alg_bytes = S * (2 * 128 * 4 + 3 * 8 * len(levels_hw) * 4 * 4)
-    cpu_model = "unknown"
+    reps, el = timed(c, args.cpu_seconds, threads, warm_seconds=1.5)
+    reps1, el1 = timed(c, min(3.0, args.cpu_seconds), 1)
+    table = {}
+    shapes_tbl = {"P1": [(16, 16), (32, 32), (64, 64)], "P2": [(16, 16), (32, 32), (64, 64), (128, 128)],
+                  "P4": [(17, 22), (33, 44), (65, 87)]}
+    for name, shp in shapes_tbl.items():
+        St = sum(h * w for h, w in shp)
+        for dist in ("U", "M"):
+            ct = make_case(seed=0, N=1, M=8, D=16, Lq=St, P=4, shapes=shp, model_like=(dist == "M"))
+            r, e = timed(ct, 1.0, threads)
+            table["%s_%s" % (name, dist)] = {"ms_per_image_layer": 1e3 * e / r, "algorithmic_GBps": alg_bytes(shp) * r / e / 1e9}
+    orc.set_threads(threads_max)
+    out = {"value": reps / el, "unit": "MSDeformAttn-forward image-layers/s", "cores": threads, "kind": "port",
+           "cpu_model": model, "physical_cores": phys, "logical_cpus": logical, "threads_used": threads,
+           "sample": "oracle/msda_oracle.c (C + OpenMP, %d threads = physical cores) forward, 1 image x %d reps, levels %s, "
+                     "S=%d, M=8 D=16 P=4 fp32, model-like locations" % (threads, reps, list(levels_hw), S),
+           "ms_per_image_layer": 1e3 * el / reps, "algorithmic_GBps": alg_bytes(levels_hw) * reps / el / 1e9,
+           "one_thread": {"value": reps1 / el1, "ms_per_image_layer": 1e3 * el1 / reps1,
+                          "algorithmic_GBps": alg_bytes(levels_hw) * reps1 / el1 / 1e9},
+           "table_all_cores": table}
     try:
-        with open("/proc/cpuinfo") as f:
-            cpu_model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
-    except (OSError, StopIteration):
-        pass
-    return {"value": reps / el, "unit": "MSDeformAttn-forward image-layers/s", "cores": threads, "kind": "port",
-            "cpu_model": cpu_model,
-            "sample": "oracle/msda_oracle.c (C + OpenMP, %d threads) forward, 1 image x %d reps, levels %s, S=%d, "
-                      "M=8 D=16 P=4 fp32, model-like locations" % (threads, reps, list(levels_hw), S),
-            "ms_per_image_layer": 1e3 * el / reps, "algorithmic_GBps": alg_bytes * reps / el / 1e9}
+        out["head_config1_cpu"] = cpu_head_config1(threads)
+    except Exception as e:      # the CPU head is an extra; never lose the bench line over it
+        out["head_config1_cpu"] = {"error": repr(e)}
+    return out
+
+
+def cpu_head_config1(threads, seconds=5.0):
+    """BASELINE.json configs[0]: single 256 x 256 tile, ResNet-18 feature shapes, 50 queries, batch 1, CPU, fp32."""
+    from pctrans_amd.config import get_cfg, resnet_output_shape
+    from pctrans_amd.meta_arch.mask_former_head import MaskFormerHead
+    from pctrans_amd.pixel_decoder.ops.modules import ms_deform_attn as msda_mod
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    prev = msda_mod.allow_cpu_reference(True)          # the dense formulation of the op, for CPU tensors only
+    try:
+        cfg = get_cfg(num_queries=50, enc_in_features=("res3", "res4", "res5"))
+        shapes = resnet_output_shape(18)
+        torch.manual_seed(0)
+        head = MaskFormerHead(**MaskFormerHead.from_config(cfg, shapes)).eval()
+        g = torch.Generator().manual_seed(1)
+        feats = {k: torch.randn(1, s.channels, 256 // s.stride, 256 // s.stride, generator=g) for k, s in shapes.items()}
+        with torch.no_grad():
+            head(feats)
+            reps, t0 = 0, time.perf_counter()
+            while True:
+                head(feats)
+                reps += 1
+                el = time.perf_counter() - t0
+                if el >= seconds:
+                    break
+        return {"value": reps / el, "unit": "samples/s", "ms_per_sample": 1e3 * el / reps, "threads": threads,
+                "workload": "configs[0]: 256x256 tile, ResNet-18 feature shapes, 3 encoder levels (8^2, 16^2, 32^2), "
+                            "50 queries, batch 1, fp32, PyTorch CPU kernels + dense MSDeformAttn formulation"}
+    finally:
+        msda_mod.allow_cpu_reference(prev)
+        torch.set_num_threads(prev_threads)
 
 
 def traffic_from_profile(args):
