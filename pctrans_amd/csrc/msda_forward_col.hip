@@ -34,6 +34,11 @@
 
 namespace pct {
 
+#ifndef PCT_COL_STREAM_NT
+#define PCT_COL_STREAM_NT 0   /* measured: nt on the record loads re-fetches the half lines two heads / two load groups share
+                                (I: 7.9 -> 9.7 GB read per launch, 1.95 -> 2.14 ms); kept as a build switch */
+#endif
+
 typedef int col_i32x4 __attribute__((ext_vector_type(4)));
 typedef float col_f32x2 __attribute__((ext_vector_type(2)));
 typedef float col_f32x4 __attribute__((ext_vector_type(4)));
@@ -124,6 +129,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
     unsigned *__restrict__ queue, unsigned long long *__restrict__ stamps = nullptr)
 {
   constexpr int P = 4, D = 16, PXB = 64, NW = BLOCK / 64;
+  // locations, weights and outputs are touched exactly once: non-temporal, so that they do not push the value lines (which
+  // neighbouring columns and the sibling head re-use) out of the XCD's L2
+  constexpr bool STREAM_NT = PCT_COL_STREAM_NT;
   // diagnostic build only (STAMP): per-phase cycle sums of wave 0, written to a buffer nothing else reads
   unsigned long long t_prev = 0, t_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto stamp = [&](int phase) {
@@ -194,7 +202,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
   }
   const int ncol = CX * CY;
   const int items = N * ncol * M;
-  const double inv_M = uni_d(1.0 / (double)M), inv_ncol = uni_d(1.0 / (double)ncol), inv_CX = uni_d(1.0 / (double)CX);
+  const double inv_ncolM = uni_d(1.0 / ((double)ncol * (double)M)), inv_2ncol = uni_d(0.5 / (double)ncol);
+  const double inv_CX = uni_d(1.0 / (double)CX);
   const double inv_2CX = uni_d(0.5 / (double)CX), inv_2CY = uni_d(0.5 / (double)CY);
   auto col_lo_f = [&](const int c, const int W, const int C, const double inv_2C) {   // == col_lo(c, W, C)
     return udiv_by(2 * c * W + C - 1, inv_2C);
@@ -231,10 +240,24 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
 
   // item -> (image, head) [uniform] and this lane's query (qv = q, or ~q of the query an idle lane shadows)
   auto decode = [&](const int it, int &b_, int &m_, int &qv_) {
-    const int bt = udiv_by(it, inv_M);
-    m_ = it - bt * M;
-    b_ = udiv_by(bt, inv_ncol);
-    const int col = bt - b_ * ncol;
+    // Item order inside an image: head PAIR outermost, then column, then the head inside the pair.  The two heads of a
+    // pair share every 128-byte line of the value tensor (64 B each) and run in adjacent workgroups; the columns of one
+    // pair follow each other, so an XCD works through one head pair's value maps (2.8 MB of lines at the north-star
+    // shape, inside its 4 MB L2) with all the neighbouring columns -- whose windows overlap -- in flight together.
+    // (With the 8 heads of a column adjacent instead, an XCD held 12 columns x 8 heads of windows at once, more than its
+    // L2: measured 1.41x / 1.92x the algorithmic bytes on the memory side for distributions I / M.)
+    b_ = udiv_by(it, inv_ncolM);
+    const int r_img = it - b_ * (ncol * M);
+    int col;
+    if (r_img < 2 * ncol * (M >> 1)) {
+      const int pr = udiv_by(r_img, inv_2ncol);
+      const int rr = r_img - pr * 2 * ncol;
+      col = rr >> 1;
+      m_ = 2 * pr + (rr & 1);
+    } else {                                                                   // odd head count: the last head alone
+      col = r_img - 2 * ncol * (M >> 1);
+      m_ = M - 1;
+    }
     const int cy = udiv_by(col, inv_CX), cx = col - cy * CX;
     int q = 0, r = tid, q_first = 0;
     bool found = false, have_first = false;
@@ -276,7 +299,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       int pi = g * 4 + ((s4 - qi) & 3);
       if (NPL % 4 != 0 && pi >= NPL) pi = g * 4;                               // (a partial last group: harmless repeat)
       const unsigned r = (unsigned)((qs[s4] < 0 ? ~qs[s4] : qs[s4]) * M + m_);
-      raw[g][s4] = *reinterpret_cast<const col_f32x4 *>(base + (size_t)(r * (unsigned)(L * P * 2) + (unsigned)(pi * 4)));
+      raw[g][s4] = STREAM_NT ? __builtin_nontemporal_load(reinterpret_cast<const col_f32x4 *>(
+                                   base + (size_t)(r * (unsigned)(L * P * 2) + (unsigned)(pi * 4))))
+                             : *reinterpret_cast<const col_f32x4 *>(base + (size_t)(r * (unsigned)(L * P * 2) + (unsigned)(pi * 4)));
     }
   };
   auto issue_loc = [&](const int b_, const int m_, const int qv_, col_f32x4 (&raw)[NGL][4]) {
@@ -374,20 +399,19 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
     // ---- pre-pass: per-level bounding box (first corners, biased by +1; the box covers x0 .. x0 + 1) ----------------
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-      float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
-#pragma unroll
-      for (int k = 0; k < P; ++k) {
-        // the very registers the gather floors.  A sample is gated in iff
-        // -1 < w_im < W: clamping to [-1, W - 0.5] maps a gated-out coordinate onto one a gated-in sample could have
-        // (NaN clamps to -1), so it can only widen the box towards the map border, never past the 1-pixel apron.
-        const float h_im = lxy[l][k][1], w_im = lxy[l][k][0];
-        const float wc = __builtin_amdgcn_fmed3f(w_im, -1.f, uni(fW[l] - 0.5f));
-        const float hc = __builtin_amdgcn_fmed3f(h_im, -1.f, uni(fH[l] - 0.5f));
-        mnx = fminf(mnx, wc);
-        mxx = fmaxf(mxx, wc);
-        mny = fminf(mny, hc);
-        mxy = fmaxf(mxy, hc);
-      }
+      // min / max over the lane's four samples on the raw pixel coordinates, then ONE clamp per lane and level (a clamp
+      // is monotone, so it commutes with min / max; v_min / v_max return the other operand for a NaN, so a NaN sample --
+      // gated out anyway -- drops out).  A sample is gated in iff -1 < w_im < W: clamping to [-1, W - 0.5] maps a
+      // gated-out coordinate onto one a gated-in sample could have, so it can only widen the box towards the map
+      // border, never past the 1-pixel apron.  The gather floors the very same registers.
+      const float mnx = __builtin_amdgcn_fmed3f(fminf(fminf(lxy[l][0][0], lxy[l][1][0]), fminf(lxy[l][2][0], lxy[l][3][0])),
+                                                -1.f, uni(fW[l] - 0.5f));
+      const float mxx = __builtin_amdgcn_fmed3f(fmaxf(fmaxf(lxy[l][0][0], lxy[l][1][0]), fmaxf(lxy[l][2][0], lxy[l][3][0])),
+                                                -1.f, uni(fW[l] - 0.5f));
+      const float mny = __builtin_amdgcn_fmed3f(fminf(fminf(lxy[l][0][1], lxy[l][1][1]), fminf(lxy[l][2][1], lxy[l][3][1])),
+                                                -1.f, uni(fH[l] - 0.5f));
+      const float mxy = __builtin_amdgcn_fmed3f(fmaxf(fmaxf(lxy[l][0][1], lxy[l][1][1]), fmaxf(lxy[l][2][1], lxy[l][3][1])),
+                                                -1.f, uni(fH[l] - 0.5f));
       unsigned lo = (unsigned)((int)floorf(mnx) + 1) | ((unsigned)((int)floorf(mny) + 1) << 16);
       unsigned hi = (unsigned)((int)floorf(mxx) + 2) | ((unsigned)((int)floorf(mxy) + 2) << 16);
       lo = wave_reduce_pk<true>(lo);
@@ -397,7 +421,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
         bb[(wave * L + l) * 2 + 1] = hi;
       }
     }
-    __builtin_amdgcn_sched_barrier(0);                                        // (keep the address arithmetic below down here)
     // ---- this item's weights (FUSED: logits): fetched now, looked at after the staging barrier.  (Behind the pre-pass:
     // anything that waits on the memory counter there -- it is in-order -- would otherwise wait for these loads too.) ---------
     col_f32x4 wraw[NGW][4];
@@ -410,7 +433,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
           int pi = g * 4 + ((s4 - qi) & 3);
           if (L % 4 != 0 && pi >= L) pi = g * 4;
           const unsigned r = (unsigned)((qs[s4] < 0 ? ~qs[s4] : qs[s4]) * M + m);
-          wraw[g][s4] = *reinterpret_cast<const col_f32x4 *>(wbase_img + (size_t)(r * (unsigned)(L * P) + (unsigned)(pi * 4)));
+          wraw[g][s4] = STREAM_NT ? __builtin_nontemporal_load(reinterpret_cast<const col_f32x4 *>(
+                                        wbase_img + (size_t)(r * (unsigned)(L * P) + (unsigned)(pi * 4))))
+                                  : *reinterpret_cast<const col_f32x4 *>(wbase_img + (size_t)(r * (unsigned)(L * P) + (unsigned)(pi * 4)));
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // boxes in LDS before the barrier
@@ -731,7 +756,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
         if (qo[s4] >= 0) {
           float *op = out + rec_img * M * D +
                       (size_t)((unsigned)(qo[s4] * M + m) * (unsigned)D + (unsigned)((((qi - s4) + (int)rho) & 3) * 4));
-          *reinterpret_cast<col_f32x4 *>(op) = w4[s4];
+          if (STREAM_NT) __builtin_nontemporal_store(w4[s4], reinterpret_cast<col_f32x4 *>(op));
+          else *reinterpret_cast<col_f32x4 *>(op) = w4[s4];
         }
       }
     }
