@@ -276,7 +276,16 @@ def spawn_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
-    return subprocess.run(cmd, env=env).returncode
+    # only the JSON line goes to this process's stdout; anything else a rank or a library prints there (gloo announces its
+    # peers on stdout, for instance) is passed on to stderr
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        if line.startswith("{") and '"metric"' in line:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
 
 
 def main():

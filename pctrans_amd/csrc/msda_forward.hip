@@ -246,10 +246,11 @@ int launch_msda_forward_special(const void *value, const int64_t *shapes, const 
   // (P2: N = 1 0.046 vs 0.040 ms, N = 2 equal, N = 4 0.089 vs 0.113 ms; P4, N = 1: 0.024 vs 0.014 ms)
   const long long per_item = P == 8 ? 128 : (sizeof(typename Traits<T>::store_t) == 2 ? 512 : 256);   // queries per item
   const bool win_small = (long long)N * ((Lq + per_item - 1) / per_item) * M < 3 * 768;
-  // the pyramid-column kernel (fp32, 4 points): one 1024-thread workgroup per CU, items of <= 1024 queries -- it needs
-  // about two items per workgroup before it beats the windowed kernel
+  // the pyramid-column kernel (fp32, 4 points): persistent grid of 768 workgroups with items of <= 256 queries.  Measured
+  // crossover against the windowed / quad-owner kernels (model-like locations, profiles/r02_small_batch.txt): with 4
+  // levels it wins from one 512^2 image on (N * S * M = 174 k); with 3 levels from about 450 k (quad-owner before that)
   if constexpr (sizeof(typename Traits<T>::store_t) == 4) {
-    const bool col_big = (long long)N * S * M >= 2LL * 256 * 900;
+    const bool col_big = (long long)N * S * M >= (L >= 4 ? 160000LL : 450000LL);
     if (choice == 4 || (choice == 0 && Lq == S && P == 4 && col_big)) {
       rc = launch_msda_forward_col(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream, ref, ref_batch_stride);
       if (rc != -100) note_msda_kernel(4);

@@ -172,7 +172,7 @@ def test_fused_front_end_on_the_windowed_kernel(MSDA, lib, shapes, P, N, shared_
 
 
 def test_fused_front_end_auto_route_at_model_batch(MSDA, lib):
-    """P2 at N = 4 is the smallest batch `auto` itself sends to the column kernel; the oracle does it in seconds."""
+    """P2 at N = 4 under `auto` (the column kernel from N = 1 on at this shape); the oracle does it in seconds."""
     _fused_check(MSDA, lib, P2, 4, 4, True, -1, K_COL, 2.0, True)
 
 
@@ -198,8 +198,8 @@ def _launch(MSDA, lib, shapes, N, P, dtype, fused=False):
 @pytest.mark.parametrize("name,shapes,N,P,dtype,fused,expect", [
     # BASELINE.json configs[0]: 256^2 tile, batch 1 (S = 1344): too small for a persistent grid
     ("cfg1_256_b1", [(8, 8), (16, 16), (32, 32)], 1, 4, torch.float32, True, K_DPP),
-    # configs[1]: 512^2, 4 levels; per-GPU batch 1 (launch-bound), 8 and the bench's 128
-    ("cfg2_512_b1", P2, 1, 4, torch.float32, True, K_DPP),
+    # configs[1]: 512^2, 4 levels; per-GPU batch 1, 8 and the bench's 128
+    ("cfg2_512_b1", P2, 1, 4, torch.float32, True, K_COL),
     ("cfg2_512_b8", P2, 8, 4, torch.float32, True, K_COL),
     ("cfg2_512_b128_plain", P2, 128, 4, torch.float32, False, K_COL),
     ("cfg2_512_b128_fused", P2, 128, 4, torch.float32, True, K_COL),
