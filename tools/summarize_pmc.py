@@ -20,6 +20,7 @@ ap.add_argument("dirs", nargs="+")
 ap.add_argument("--kernel", default="msda_forward_win")
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--levels", type=int, default=4)
+ap.add_argument("--dist", default=None, help="location distribution of the bench run (M / I)")
 ap.add_argument("--skip-first", type=int, default=0, help="dispatches to drop per counter (warm-up)")
 ap.add_argument("--out", required=True)
 a = ap.parse_args()
@@ -45,6 +46,9 @@ rec = {
     "batch": a.batch,
     "levels": a.levels,
 }
+if a.dist:
+    rec["location_dist"] = a.dist
+    rec["workload"] += ", sampling offsets: distribution " + a.dist
 for k, v in mean.items():
     rec[k + ("_KB" if k.endswith("_SIZE") else "")] = v
 if "TCC_EA0_RDREQ_128B_sum" in mean:
