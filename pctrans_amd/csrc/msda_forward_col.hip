@@ -792,12 +792,13 @@ int launch_msda_forward_col(const void *value, const int64_t *shapes, const int6
   // 384 x 2 (~75 KB, 168 registers), 256 x 3 (~50 KB, 168 registers).  With more than one workgroup per CU the memory
   // phases of one (records, staging) overlap the gather of the others.
   static const int block_env = [] { const char *e = getenv("PCT_COL_BLOCK"); const int v = e ? atoi(e) : 0;
-                                    return (v == 256 || v == 384 || v == 512 || v == 1024) ? v : 256; }();
+                                    return (v == 256 || v == 384 || v == 512 || v == 768 || v == 1024) ? v : 256; }();
   static const int pool_env = [] { const char *e = getenv("PCT_COL_POOL_KB"); return e ? atoi(e) : 0; }();
   const int BLOCKV = block_env;
-  const int pool_max = BLOCKV == 1024 ? 158 : 78;
-  const int pool_kb = (pool_env >= 16 && pool_env <= pool_max) ? pool_env : (BLOCKV == 1024 ? 150 : (BLOCKV == 256 ? 50 : 74));
-  const int wg_per_cu = BLOCKV == 1024 ? 1 : ((BLOCKV == 256 && pool_kb <= 52) ? 3 : 2);
+  const bool one_wg = BLOCKV == 1024 || BLOCKV == 768;
+  const int pool_max = one_wg ? 158 : 78;
+  const int pool_kb = (pool_env >= 16 && pool_env <= pool_max) ? pool_env : (one_wg ? 150 : (BLOCKV == 256 ? 50 : 74));
+  const int wg_per_cu = one_wg ? 1 : ((BLOCKV == 256 && pool_kb <= 52) ? 3 : 2);
   const int pool_px = pool_kb * 1024 / 64;
   const size_t lds = (size_t)pool_px * 64 + ((size_t)(BLOCKV / 64) * L * 2 + 4) * sizeof(unsigned);   // pool, boxes, queue words
   const dim3 grid(256 * wg_per_cu), block(BLOCKV);
@@ -817,6 +818,7 @@ int launch_msda_forward_col(const void *value, const int64_t *shapes, const int6
 #define PCT_COL_B(L_, FU_, ST_)                                \
   do {                                                         \
     if (BLOCKV == 1024) PCT_COL_K(L_, FU_, 1024, ST_);         \
+    else if (BLOCKV == 768) PCT_COL_K(L_, FU_, 768, ST_);      \
     else if (BLOCKV == 512) PCT_COL_K(L_, FU_, 512, ST_);      \
     else if (BLOCKV == 384) PCT_COL_K(L_, FU_, 384, ST_);      \
     else PCT_COL_K(L_, FU_, 256, ST_);                         \
