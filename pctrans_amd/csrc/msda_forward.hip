@@ -202,6 +202,9 @@ int launch_msda_forward_dpp(const void *, const int64_t *, const int64_t *, cons
 
 int launch_msda_forward_col(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
                             int, int, int, int, void *, hipStream_t, const float *, long long);   // msda_forward_col.hip
+template <typename T>
+int launch_msda_forward_col16(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
+                              int, int, int, int, void *, hipStream_t, const float *, long long);  // msda_forward_col16.hip
 
 // Kernel choice for PCTrans' geometry.  Default "auto": the windowed-LDS kernel when the queries are the pyramid's
 // own pixels (Lq == S: neighbouring queries sample neighbouring texels, the case it is built for) and the problem fills
@@ -253,6 +256,15 @@ int launch_msda_forward_special(const void *value, const int64_t *shapes, const 
     const bool col_big = (long long)N * S * M >= (L >= 4 ? 160000LL : 450000LL);
     if (choice == 4 || (choice == 0 && Lq == S && P == 4 && col_big)) {
       rc = launch_msda_forward_col(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream, ref, ref_batch_stride);
+      if (rc != -100) note_msda_kernel(4);
+    }
+  }
+  if constexpr (sizeof(typename Traits<T>::store_t) == 2) {
+    // 16-bit values: the column kernel's 16-bit variant (4 or 8 points; two lanes per (query, head) with 8 points)
+    const bool col_big = (long long)N * S * M * (P / 4) >= (L >= 4 ? 160000LL : 450000LL);
+    if (choice == 4 || (choice == 0 && Lq == S && (P == 4 || P == 8) && col_big)) {
+      rc = launch_msda_forward_col16<T>(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream, ref,
+                                        ref_batch_stride);
       if (rc != -100) note_msda_kernel(4);
     }
   }

@@ -208,8 +208,9 @@ def _launch(MSDA, lib, shapes, N, P, dtype, fused=False):
     # configs[3]: BBBC 520x696 test tiles, 3 levels; batch 8
     ("cfg4_bbbc_b8", P4, 8, 4, torch.float32, True, K_COL),
     # configs[4]: 1024^2, 5 levels, 8 points, fp16 (S = 87296)
-    ("cfg5_1024_b1_f16", P3, 1, 8, torch.float16, False, K_DPP),
-    ("cfg5_1024_b1_bf16", P3, 1, 8, torch.bfloat16, False, K_DPP),
+    ("cfg5_1024_b1_f16", P3, 1, 8, torch.float16, False, K_COL),
+    ("cfg5_1024_b1_bf16", P3, 1, 8, torch.bfloat16, False, K_COL),
+    ("cfg2_512_b8_bf16_value", P2, 8, 4, torch.bfloat16, False, K_COL),
 ])
 def test_auto_kernel_choice_per_baseline_config(MSDA, lib, name, shapes, N, P, dtype, fused, expect):
     """Pins `auto`'s routing, so that a threshold change cannot silently strand a kernel without oracle coverage: every
@@ -227,16 +228,16 @@ def test_auto_kernel_choice_per_baseline_config(MSDA, lib, name, shapes, N, P, d
     (1, P3, dict(model_like=True)),                       # BASELINE.json configs[4] at its true size: S = 87 296
 ])
 def test_config5_16bit_P8_L5_default_route_vs_oracle(MSDA, lib, tdt, eps, N, shapes, kw):
-    """fp16 / bf16 value, 5 levels, 8 points through whatever `auto` launches (the quad-owner kernel): fp32 oracle on
-    the same 16-bit-rounded value, error within output rounding (new capability: the reference op is fp32 / fp64 only,
-    cu:69,139)."""
+    """fp16 / bf16 value, 5 levels, 8 points through whatever `auto` launches (small: the quad-owner kernel; configs[4]
+    at its true size: the 16-bit column kernel): fp32 oracle on the same 16-bit-rounded value, error within output
+    rounding (new capability: the reference op is fp32 / fp64 only, cu:69,139)."""
     S = n_px(shapes)
     c = make_case(seed=131, N=N, M=8, D=16, Lq=S, P=8, shapes=shapes, **kw)
     v16 = torch.from_numpy(c["value"]).to(tdt)
     want = orc.forward(v16.float().numpy(), c["shapes"], c["starts"], c["loc"], c["attn"])
     lib.pct_msda_set_kernel_choice(-1)
     got = MSDA.ms_deform_attn_forward(v16.cuda(), dev(c["shapes"]), dev(c["starts"]), dev(c["loc"]), dev(c["attn"]), 64)
-    assert lib.pct_msda_last_kernel() == K_DPP and got.dtype == tdt
+    assert lib.pct_msda_last_kernel() == (K_COL if N * S * 8 * 2 >= 160000 else K_DPP) and got.dtype == tdt
     err = np.abs(got.float().cpu().numpy() - want)
     assert np.all(err <= eps * np.abs(want) + 1e-5), float(err.max())
 
@@ -273,7 +274,7 @@ def test_config5_fullsize_properties(MSDA, lib):
     idx = int(starts_of(sh)[4]) + py * w + px
     want = torch.gather(v1, 1, idx[..., None].expand(N, S, M, D))
     assert torch.equal(out, want)
-    assert lib.pct_msda_last_kernel() == K_DPP
+    assert lib.pct_msda_last_kernel() == K_COL
 
 
 # ---------------------------------------------------------------- the module with a padding mask, on the device
@@ -331,3 +332,32 @@ def test_batch_256_is_chunked_inside_the_library_not_rerouted(MSDA, lib):
     del off, lg
     gotp = MSDA.ms_deform_attn_forward(v, shd, std, loc2.repeat(N // 2, 1, 1, 1, 1, 1), w2.repeat(N // 2, 1, 1, 1, 1), 128)
     assert float((gotp.view(N // 2, 2, S, M * D) - want2p[None]).abs().max()) <= 1e-5
+
+
+# ---------------------------------------------------------------- the 16-bit column kernel (msda_forward_col16.hip), forced
+COL16_CASES = [
+    # (id, P, shapes, make_case kwargs)
+    ("c16_P8_L5_model", 8, [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64)], dict(N=2, model_like=True)),
+    ("c16_P8_L5_edges", 8, [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64)], dict(N=1, lo=-0.2, hi=1.2)),
+    ("c16_P8_L4_init_like", 8, P2, dict(N=1, init_like=True)),
+    ("c16_P8_L3_nonpow2_sigma6", 8, P4, dict(N=2, model_like=True, px_sigma=6.0)),
+    ("c16_P4_L4_model", 4, P2, dict(N=1, model_like=True)),
+    ("c16_P4_L4_init_like", 4, P2, dict(N=2, init_like=True)),
+    ("c16_P4_L3_uniform", 4, P1, dict(N=2)),
+    ("c16_P4_L5_model", 4, [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64)], dict(N=2, model_like=True, px_sigma=1.0)),
+    ("c16_P8_M3_heads", 8, [(9, 12), (18, 24), (36, 48)], dict(N=2, M=3, model_like=True)),
+]
+
+
+@pytest.mark.parametrize("tdt,eps", [(torch.float16, 2.0 ** -11), (torch.bfloat16, 2.0 ** -8)])
+@pytest.mark.parametrize("cid,P,shapes,kw", COL16_CASES, ids=[c[0] for c in COL16_CASES])
+def test_column_kernel_16bit_vs_oracle(MSDA, lib, cid, P, shapes, kw, tdt, eps):
+    kw = dict(dict(M=8), **kw)
+    c = make_case(seed=141, D=16, Lq=n_px(shapes), P=P, shapes=shapes, **kw)
+    v16 = torch.from_numpy(c["value"]).to(tdt)
+    want = orc.forward(v16.float().numpy(), c["shapes"], c["starts"], c["loc"], c["attn"])
+    with force(lib, K_COL):
+        got = MSDA.ms_deform_attn_forward(v16.cuda(), dev(c["shapes"]), dev(c["starts"]), dev(c["loc"]), dev(c["attn"]), 64)
+        assert lib.pct_msda_last_kernel() == K_COL and got.dtype == tdt
+    err = np.abs(got.float().cpu().numpy() - want)
+    assert np.all(err <= eps * np.abs(want) + 1e-5), float(err.max())
