@@ -50,4 +50,62 @@ __device__ __forceinline__ int udiv_by(const int n, const double inv)
   return __builtin_amdgcn_readfirstlane((int)(((double)n + 0.5) * inv));
 }
 
+// floor(n / d) for uniform 0 <= n < 2^31, 1 <= d < 2^31, entirely on the scalar unit (s_mul_hi_u32): with
+// m = floor((2^32 - 1) / d) the estimate q' = floor(n * m / 2^32) falls short of n / d by less than n / 2^32 < 1/2, so it
+// is the quotient or one below it, and one comparison of the remainder settles which.  (The double-precision form
+// above costs four vector instructions and a readfirstlane; an item decode holds some twenty divisions.)
+struct UDiv {
+  unsigned d, m;
+};
+__device__ __forceinline__ UDiv make_udiv(const int d)
+{
+  const unsigned du = (unsigned)__builtin_amdgcn_readfirstlane(d);
+  return UDiv{du, (unsigned)__builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu / du))};
+}
+__device__ __forceinline__ int udiv_s(const int n, const UDiv u)
+{
+  const unsigned q = __umulhi((unsigned)n, u.m);
+  const unsigned r = (unsigned)n - q * u.d;
+  return (int)(q + (r >= u.d ? 1u : 0u));
+}
+
+// floor to int in one instruction (the compiler emits v_floor_f32 + v_cvt_i32_f32)
+__device__ __forceinline__ int cvt_flr(const float x)
+{
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// A wave's bounding box in ONE reduction.  lo = packed (u16, u16) low corner, hi = packed high corner: the maximum is
+// taken as the minimum of complements, and after a half-wave swap lanes 0-31 reduce the low corners of all 64 lanes
+// while lanes 32-63 reduce the complemented high corners.  Returns, in lane 31, min(lo) and, in lane 63, ~max(hi)
+// (other lanes: partial results).  12 vector instructions against 30 for two separate reductions.
+__device__ __forceinline__ unsigned wave_reduce_box(const unsigned lo, const unsigned hi)
+{
+  const auto s = __builtin_amdgcn_permlane32_swap(lo, ~hi, false, false);
+  unsigned v = pk_min(s[0], s[1]);
+  v = pk_min(v, dpp_u<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = pk_min(v, dpp_u<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = pk_min(v, dpp_u<0x141>(v));   // row_half_mirror
+  v = pk_min(v, dpp_u<0x140>(v));   // row_mirror
+  v = pk_min(v, dpp_u<0x142>(v));   // row_bcast:15 -- rows 1 and 3 take in lane 15 of rows 0 and 2
+  return v;
+}
+
+// The workgroup's box from the NW per-wave records {min lo, ~max hi} (8 bytes each, contiguous, 16-byte aligned): every
+// lane reads all of them (LDS broadcast) and reduces in registers; the result is uniform.
+template <int NW>
+__device__ __forceinline__ void block_box(const unsigned *rec, unsigned &lo, unsigned &hi)
+{
+  unsigned a = 0xFFFFFFFFu, b = 0xFFFFFFFFu;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    a = pk_min(a, rec[2 * w]);
+    b = pk_min(b, rec[2 * w + 1]);
+  }
+  lo = (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+  hi = ~(unsigned)__builtin_amdgcn_readfirstlane((int)b);
+}
+
 }  // namespace pct

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char *pool = smem_raw;                                              // level windows, 32 B per head-pixel
-  unsigned *bb = reinterpret_cast<unsigned *>(smem_raw + (size_t)pool_px * PXB);   // [NW][L][2] per-wave boxes
+  unsigned *bb = reinterpret_cast<unsigned *>(smem_raw + (size_t)pool_px * PXB);   // [L][NW][2] per-wave boxes {min lo, ~max hi}
   unsigned *next_idx = bb + NW * L * 2;                                        // [0] next item, [1] counter value fetched
 
   int tid = threadIdx.x;
@@ -93,11 +93,10 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
   }
   const int ncol = CX * CY;
   const int items = N * ncol * M;
-  const double inv_ncolM = uni_d(1.0 / ((double)ncol * (double)M)), inv_2ncol = uni_d(0.5 / (double)ncol);
-  const double inv_CX = uni_d(1.0 / (double)CX);
-  const double inv_2CX = uni_d(0.5 / (double)CX), inv_2CY = uni_d(0.5 / (double)CY);
-  auto col_lo_f = [&](const int c, const int W, const int C, const double inv_2C) {   // == col_lo(c, W, C)
-    return udiv_by(2 * c * W + C - 1, inv_2C);
+  const UDiv dv_ncolM = make_udiv(ncol * M), dv_2ncol = make_udiv(2 * ncol), dv_CX = make_udiv(CX);
+  const UDiv dv_2CX = make_udiv(2 * CX), dv_2CY = make_udiv(2 * CY);
+  auto col_lo_f = [&](const int c, const int W, const int C, const UDiv dv_2C) {   // == col_lo(c, W, C), scalar unit
+    return udiv_s(2 * c * W + C - 1, dv_2C);
   };
 
   // pixels 0 and 1 of the pool are zeros: gated-out samples read them
@@ -119,11 +118,11 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
   // item -> (image, head) [uniform] and this lane's query (qv = q, or ~q of the query an idle lane shadows); order inside
   // an image: head pair, column, head in the pair (msda_forward_col.hip)
   auto decode = [&](const int it, int &b_, int &m_, int &qv_) {
-    b_ = udiv_by(it, inv_ncolM);
+    b_ = udiv_s(it, dv_ncolM);
     const int r_img = it - b_ * (ncol * M);
     int col;
     if (r_img < 2 * ncol * (M >> 1)) {
-      const int pr = udiv_by(r_img, inv_2ncol);
+      const int pr = udiv_s(r_img, dv_2ncol);
       const int rr = r_img - pr * 2 * ncol;
       col = rr >> 1;
       m_ = 2 * pr + (rr & 1);
@@ -131,14 +130,14 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
       col = r_img - 2 * ncol * (M >> 1);
       m_ = M - 1;
     }
-    const int cy = udiv_by(col, inv_CX), cx = col - cy * CX;
+    const int cy = udiv_s(col, dv_CX), cx = col - cy * CX;
     int q = 0, r = tid / HALVES, q_first = 0;
     bool found = false, have_first = false;
 #pragma unroll
     for (int ll = 0; ll < L; ++ll) {
       const int l = L - 1 - ll;
-      const int xa = col_lo_f(cx, Ws[l], CX, inv_2CX), nx = col_lo_f(cx + 1, Ws[l], CX, inv_2CX) - xa;
-      const int ya = col_lo_f(cy, Hs[l], CY, inv_2CY), ny = col_lo_f(cy + 1, Hs[l], CY, inv_2CY) - ya;
+      const int xa = col_lo_f(cx, Ws[l], CX, dv_2CX), nx = col_lo_f(cx + 1, Ws[l], CX, dv_2CX) - xa;
+      const int ya = col_lo_f(cy, Hs[l], CY, dv_2CY), ny = col_lo_f(cy + 1, Hs[l], CY, dv_2CY) - ya;
       const int cnt = nx * ny;
       if (!have_first && cnt > 0) { have_first = true; q_first = St[l] + ya * Ws[l] + xa; }
       const bool in = !found && r < cnt;
@@ -236,14 +235,10 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
                                                 -1.f, uni(fH[l] - 0.5f));
       const float mxy = __builtin_amdgcn_fmed3f(fmaxf(fmaxf(lxy[l][0][1], lxy[l][1][1]), fmaxf(lxy[l][2][1], lxy[l][3][1])),
                                                 -1.f, uni(fH[l] - 0.5f));
-      unsigned lo = (unsigned)((int)floorf(mnx) + 1) | ((unsigned)((int)floorf(mny) + 1) << 16);
-      unsigned hi = (unsigned)((int)floorf(mxx) + 2) | ((unsigned)((int)floorf(mxy) + 2) << 16);
-      lo = wave_reduce_pk<true>(lo);
-      hi = wave_reduce_pk<false>(hi);
-      if (lane == 0) {
-        bb[(wave * L + l) * 2] = lo;
-        bb[(wave * L + l) * 2 + 1] = hi;
-      }
+      const unsigned lo = (unsigned)(cvt_flr(mnx) + 1) | ((unsigned)(cvt_flr(mny) + 1) << 16);
+      const unsigned hi = (unsigned)(cvt_flr(mxx) + 2) | ((unsigned)(cvt_flr(mxy) + 2) << 16);
+      const unsigned red = wave_reduce_box(lo, hi);                 // lane 31: min lo, lane 63: ~max hi
+      if ((lane & 31) == 31) bb[(l * NW + wave) * 2 + (lane >> 5)] = red;
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- this lane's weights (FUSED: logits): its 4 points of every level, 16 bytes per level ------------------------
@@ -275,11 +270,8 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
     {
 #pragma unroll
       for (int l = 0; l < L; ++l) {
-        const int ln = tid & 63;
-        unsigned lo = ln < NW ? bb[(ln * L + l) * 2] : 0xFFFFFFFFu;
-        unsigned hi = ln < NW ? bb[(ln * L + l) * 2 + 1] : 0u;
-        lo = __builtin_amdgcn_readfirstlane(wave_reduce_pk<true>(lo));
-        hi = __builtin_amdgcn_readfirstlane(wave_reduce_pk<false>(hi));
+        unsigned lo, hi;
+        block_box<NW>(bb + l * NW * 2, lo, hi);
         const int x0 = (int)(lo & 0xFFFFu) - 1, y0 = (int)(lo >> 16) - 1;
         const int x1 = (int)(hi & 0xFFFFu) - 1, y1 = (int)(hi >> 16) - 1;
         const bool empty = x0 > x1 || y0 > y1;
@@ -347,10 +339,9 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
       pix[0] = g.gate ? pix[0] : 0.f;
       pix[1] = g.gate ? pix[1] : 0.f;
       const float wgt = g.gate ? wts[l][k] : 0.f;
-      const col_f32x2 flo = {floorf(pix[0]), floorf(pix[1])};
-      g.x0 = (int)flo[0];
-      g.y0 = (int)flo[1];
-      const col_f32x2 lo = pix - flo;
+      g.x0 = cvt_flr(pix[0]);
+      g.y0 = cvt_flr(pix[1]);
+      const col_f32x2 lo = {__builtin_amdgcn_fractf(pix[0]), __builtin_amdgcn_fractf(pix[1])};
       const col_f32x2 hi = col_f32x2{1.f, 1.f} - lo;
       const col_f32x2 t = {hi[0] * wgt, lo[0] * wgt};
       g.g12 = t * col_f32x2{hi[1], hi[1]};
