@@ -52,22 +52,22 @@ def discriminative_loss(embedding, seg_gt, delta_v=0.5, delta_d=3, alpha=1, beta
     dist_loss = embedding.new_zeros(())
     reg_loss = embedding.new_zeros(())
     for b in range(batch_size):
-        emb_b, gt_b = embedding[b], seg_gt[b]
-        labels = torch.unique(gt_b)
-        labels = labels[labels != 0]
-        num_id = len(labels)
+        emb_b, gt_b = embedding[b].reshape(embed_dim, -1), seg_gt[b].reshape(-1)
+        labels, inv = torch.unique(gt_b, return_inverse=True)                   # ascending: the reference's loop order
+        keep = labels != 0
+        num_id = int(keep.sum())
         if num_id == 0:
             zero = embedding.sum() * 0
             var_loss, dist_loss, reg_loss = var_loss + zero, dist_loss + zero, reg_loss + zero
             continue
-        centroids = []
-        for idx in labels:
-            m = gt_b == idx
-            emb_i = emb_b[:, m]
-            mean_i = emb_i.mean(dim=1)
-            centroids.append(mean_i)
-            var_loss = var_loss + torch.mean((torch.norm(emb_i - mean_i.reshape(embed_dim, 1), dim=0) - delta_v) ** 2) / num_id
-        centroids = torch.stack(centroids)
+        # all instances at once: membership as a one-hot [pixels, labels] matrix, so centroids and per-instance means are
+        # two small matrix products (deterministic, unlike scatter-adds) instead of ~8 launches per instance
+        member = F.one_hot(inv, labels.numel()).to(emb_b.dtype)
+        count = member.sum(0)
+        mean = (emb_b @ member) / count                                          # [E, labels]
+        spread = (torch.norm(emb_b - mean[:, inv], dim=0) - delta_v) ** 2        # [pixels]
+        var_loss = var_loss + ((spread @ member) / count)[keep].sum() / num_id
+        centroids = mean[:, keep].t()                                            # [num_id, E]
         if num_id > 1:
             d = torch.norm(centroids.reshape(-1, 1, embed_dim) - centroids.reshape(1, -1, embed_dim), dim=2)
             d = d + torch.eye(num_id, dtype=d.dtype, device=d.device) * delta_d
@@ -97,6 +97,16 @@ def _contrast_logsumexp(pred, label):
     n = pred.shape[1]
     x = F.pad(pred_neg.repeat(1, n) - torch.repeat_interleave(pred_pos, n, dim=1), (0, 1), "constant", 0)
     return torch.logsumexp(x, dim=1)
+
+
+def _contrast_softplus(scores, n_pos):
+    """The same loss for a batch of items whose first n_pos[i] columns are the positives: the double sum factorises,
+    log(1 + sum_n e^{s_n} * sum_p e^{-s_p}) = softplus(logsumexp_neg(s) + logsumexp_pos(-s)).  scores [I, K] -> [I].
+    (An item without negatives gives logsumexp over nothing = -inf and a loss of 0, like the reference's lone padded 0.)"""
+    pos = torch.arange(scores.shape[1], device=scores.device)[None, :] < n_pos[:, None]
+    lse_neg = torch.logsumexp(scores.masked_fill(pos, float("-inf")), dim=1)
+    lse_pos = torch.logsumexp((-scores).masked_fill(~pos, float("-inf")), dim=1)
+    return F.softplus(lse_neg + lse_pos)
 
 
 class SetCriterion(nn.Module):
@@ -143,6 +153,12 @@ class SetCriterion(nn.Module):
         items = outputs["pred_qd_query"]
         if len(items) == 0:
             return {"loss_reid_query": 0, "loss_reid_query_aux": 0}
+        bt = getattr(items, "batched", None)
+        if bt is not None:                       # all items at once (query_contrast.ContrastItems)
+            contras = _contrast_softplus(bt["contrast"] / 2.0, bt["n_pos"]).sum()
+            sq = torch.abs(bt["aux_consin"] - bt["aux_label"]) ** 2
+            aux = ((sq[bt["aux_rows"]] * bt["aux_valid"]).sum(1) / bt["aux_count"]).sum()
+            return {"loss_reid_query": contras / len(items), "loss_reid_query_aux": aux / len(items)}
         contras, aux = 0, 0
         for it in items:
             contras = contras + _contrast_logsumexp(it["contrast"].permute(1, 0) / 2.0, it["label"].unsqueeze(0))
@@ -153,6 +169,9 @@ class SetCriterion(nn.Module):
         items = outputs["pred_qd_mask"]
         if len(items) == 0:
             return {"loss_reid_mask": 0}
+        bt = getattr(items, "batched", None)
+        if bt is not None:
+            return {"loss_reid_mask": _contrast_softplus(bt["contrast"] / 0.5, bt["n_pos"]).sum() / len(items)}
         contras = 0
         for it in items:
             contras = contras + _contrast_logsumexp(it["contrast"].permute(1, 0) / 0.5, it["label"].unsqueeze(0))

@@ -37,11 +37,56 @@ class Point_HungarianMatcher(nn.Module):
         assert cost_mask != 0 or cost_dice != 0, "all costs cant be 0"
         self.num_points = num_points
         self.device_lsap = True            # CUDA inputs: assign on the device; False = scipy on the host (reference)
+        self.batch_images = True           # one cost pass for the whole batch when the target masks share a size
         self.pending_status = []
+
+    def _batched_costs(self, outputs, targets):
+        """All images of the batch in one pass -- when their target masks share one size: the predicted masks are the
+        channels of ONE grid_sample, the targets (padded to the largest instance count) of another, and the costs are
+        batched contractions.  Same random points as the per-image loop (one torch.rand(1, P, 2) per image, in order).
+        -> (cost [B, Q, Gmax] with zeros past an image's count, counts) or None when the sizes differ."""
+        pred = outputs["pred_masks"]
+        bs, num_queries = pred.shape[:2]
+        counts = [int(t["masks"].shape[0]) for t in targets]
+        sizes = {tuple(t["masks"].shape[-2:]) for t in targets}
+        if bs == 0 or len(sizes) != 1 or max(counts) == 0:
+            return None
+        gmax = max(counts)
+        coords = torch.cat([torch.rand(1, self.num_points, 2, device=pred.device) for _ in range(bs)])
+        if min(counts) == gmax:
+            tgt = torch.stack([t["masks"] for t in targets]).to(pred)
+        else:
+            tgt = pred.new_zeros((bs, gmax) + next(iter(sizes)))
+            for b, t in enumerate(targets):
+                tgt[b, :counts[b]] = t["masks"]
+        tgt_pts = point_sample(tgt, coords, align_corners=False)                # [B, Gmax, P]
+        out_pts = point_sample(pred, coords, align_corners=False)               # [B, Q, P]
+        with torch.autocast(device_type=pred.device.type, enabled=False):
+            out_pts, tgt_pts = out_pts.float(), tgt_pts.float()
+            hw = out_pts.shape[2]
+            pos = F.binary_cross_entropy_with_logits(out_pts, torch.ones_like(out_pts), reduction="none")
+            neg = F.binary_cross_entropy_with_logits(out_pts, torch.zeros_like(out_pts), reduction="none")
+            ce = (torch.einsum("bnc,bmc->bnm", pos, tgt_pts) + torch.einsum("bnc,bmc->bnm", neg, (1 - tgt_pts))) / hw
+            prob = out_pts.sigmoid()
+            numerator = 2 * torch.einsum("bnc,bmc->bnm", prob, tgt_pts)
+            denominator = prob.sum(-1)[:, :, None] + tgt_pts.sum(-1)[:, None, :]
+            C = self.cost_mask * ce + self.cost_dice * (1 - (numerator + 1) / (denominator + 1))
+        return C, counts
 
     @torch.no_grad()
     def memory_efficient_forward(self, outputs, targets):
         bs, num_queries = outputs["pred_masks"].shape[:2]
+        if self.batch_images:
+            got = self._batched_costs(outputs, targets)
+            if got is not None:
+                C, counts = got
+                if (self.device_lsap and C.is_cuda and max(counts) <= num_queries and num_queries <= 1024
+                        and max(counts) <= 512):
+                    return self._assign_padded(C, counts)
+                C = C.cpu()
+                indices = [linear_sum_assignment(C[b, :, :g]) for b, g in enumerate(counts)]
+                return [(torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64))
+                        for i, j in indices]
         costs = []
         for b in range(bs):
             out_mask = outputs["pred_masks"][b][:, None]                      # [Q, 1, H, W]
@@ -75,6 +120,11 @@ class Point_HungarianMatcher(nn.Module):
         for b, C in enumerate(costs):
             if counts[b]:
                 padded[b, :, :counts[b]] = C
+        return self._assign_padded(padded, counts)
+
+    def _assign_padded(self, padded, counts):
+        from .. import fused_ops
+        dev = padded.device
         rows, status = fused_ops.lsap(padded, torch.tensor(counts, dtype=torch.int32).to(dev, non_blocking=True))
         self.pending_status.append(status)
         if len(self.pending_status) > 256:             # nobody called check(): fold the backlog into one flag tensor
