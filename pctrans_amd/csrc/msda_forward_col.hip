@@ -541,45 +541,70 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
         }(), ...);
       }(std::make_integer_sequence<int, P>{});
     };
-    // ... or through the buffer descriptor (a level whose box exceeds the pool): out-of-map corners get an out-of-range
-    // offset and read zeros
+    // ... or from global memory (a level whose box exceeds the pool), through the buffer descriptor: out-of-map corners
+    // get an out-of-range offset and read zeros.  A head-pixel is 64 contiguous bytes; fetched lane by lane, every
+    // 16-byte access of a wave instruction touches a different 128-byte line and the texture addresser serialises the 64
+    // tag look-ups (measured: uniformly random locations ran at 0.064 of the roofline, half the windowed kernel's rate).
+    // So the QUAD works on one member's sample at a time: the member's four corner offsets and weights are broadcast
+    // (DPP), lane c fetches piece (s - c) % 4 of every corner of member s's sample -- the quad reads whole 64-byte
+    // pixels, 16 look-ups per instruction -- and accumulates "its piece of member s's sum".  After the level the 4 x 4
+    // block of pieces is transposed back (as the record loads are) and added to the lane's own accumulators.
+    // Measured at the north-star shape, uniformly random locations: 13.9 -> 5.3 ms; distributions I / M pay < 1 % (same
+    // box A/B).  (As a real, non-inlined function the kernel ran at half speed on EVERY input: scratch set-up and
+    // call-clobbered registers.  With two or four members' fetches in flight the hot path picked up spills whose reloads
+    // wait on the memory counter behind the prefetched records: +5 % on I / M, and 6.1 ms on U.  One member at a time is
+    // spill-free at 4 levels and the fastest on U.)
     auto gather_level_global = [&](auto lc) {
       constexpr int l = decltype(lc)::value;
       const int H = Hs[l], W = Ws[l];
+      constexpr unsigned OOB = 0x80000000u;                                    // S * M * D * 4 < 2^31 (C ABI check)
+      const unsigned MDb = (unsigned)MD * 4u;
+      col_f32x2 part[4][2];                                                    // [member s]: piece (s - qi) % 4 of s's sum
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) part[s4][0] = part[s4][1] = col_f32x2{0.f, 0.f};
       [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
         ([&] {
           const Geo g = geometry(lc, std::integral_constant<int, Ks>{});
-          constexpr unsigned OOB = 0x80000000u;                                // S * M * D * 4 < 2^31 (C ABI check)
           const bool top = g.gate && g.y0 >= 0, bot = g.gate && g.y0 + 1 <= H - 1;
           const bool lft = g.x0 >= 0, rgt = g.x0 + 1 <= W - 1;
-          const unsigned MDb = (unsigned)MD * 4u;
           const unsigned a = (unsigned)(St[l] + g.y0 * W + g.x0) * MDb + (unsigned)(m * D) * 4u;
           const unsigned o1 = (top && lft) ? a : OOB, o2 = (top && rgt) ? a + MDb : OOB;
           const unsigned o3 = (bot && lft) ? a + (unsigned)W * MDb : OOB, o4 = (bot && rgt) ? a + (unsigned)W * MDb + MDb : OOB;
-          {
-            col_f32x4 va[4], vb[4];
+          [&]<int... Ss>(std::integer_sequence<int, Ss...>) {                    // one member at a time (16 registers of data)
+            ([&] {
+              constexpr int CT = BcastCtrl<4, Ss>::value;
+              const unsigned pc = (unsigned)((Ss - qi) & 3) << 4;              // (an out-of-range offset stays out of range)
+              col_f32x4 v[4];
+              v[0] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(dpp_u<CT>(o1) + pc), 0, 0));
+              v[1] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(dpp_u<CT>(o2) + pc), 0, 0));
+              v[2] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(dpp_u<CT>(o3) + pc), 0, 0));
+              v[3] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(dpp_u<CT>(o4) + pc), 0, 0));
+              const float w[4] = {dpp_f<CT>(g.g12[0]), dpp_f<CT>(g.g12[1]), dpp_f<CT>(g.g34[0]), dpp_f<CT>(g.g34[1])};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              va[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o1 + rot[j]), 0, 0));
-              vb[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o2 + rot[j]), 0, 0));
-            }
-            fma_row(va, vb, g.g12[0], g.g12[1]);
-          }
-          pin_acc();
-          __builtin_amdgcn_sched_barrier(0);
-          {
-            col_f32x4 va[4], vb[4];
+              for (int c4 = 0; c4 < 4; ++c4)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              va[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o3 + rot[j]), 0, 0));
-              vb[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o4 + rot[j]), 0, 0));
-            }
-            fma_row(va, vb, g.g34[0], g.g34[1]);
-          }
-          pin_acc();
-          __builtin_amdgcn_sched_barrier(0);
+                for (int e = 0; e < 2; ++e)
+                  part[Ss][e] = __builtin_elementwise_fma(col_f32x2{w[c4], w[c4]},
+                                                          col_f32x2{v[c4][2 * e], v[c4][2 * e + 1]}, part[Ss][e]);
+              asm volatile("" : "+v"(part[0][0]), "+v"(part[0][1]), "+v"(part[1][0]), "+v"(part[1][1]), "+v"(part[2][0]),
+                                "+v"(part[2][1]), "+v"(part[3][0]), "+v"(part[3][1]));
+              __builtin_amdgcn_sched_barrier(0);
+            }(), ...);
+          }(std::make_integer_sequence<int, 4>{});
         }(), ...);
       }(std::make_integer_sequence<int, P>{});
+      col_f32x4 x[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) x[s4] = col_f32x4{part[s4][0][0], part[s4][0][1], part[s4][1][0], part[s4][1][1]};
+      quad_transpose_in(x, qi0, qi1);                                          // x[k] = piece k of this lane's own sum
+      rot_regs(x, rho & 1u, rho & 2u);                                         // x[j] = piece (j + rho) % 4: the slot order
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        acc[j4][0] += col_f32x2{x[j4][0], x[j4][1]};
+        acc[j4][1] += col_f32x2{x[j4][2], x[j4][3]};
+      }
+      pin_acc();
+      __builtin_amdgcn_sched_barrier(0);
     };
 
     // stage the windows of one phase: LDS-DMA (buffer_load_dwordx4 ... lds), no VGPR round trip, every piece in flight at
