@@ -444,6 +444,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       }
     }
 
+    int woff[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) woff[l] = wbase[l] - wy0[l] * wwid[l] - wx0[l];
     float wts[L][P];
     stamp(2);
     const float *vimg = value + rec_img * MD + m * D;                        // this image, this head
@@ -494,11 +497,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       const float wgt = g.gate ? wts[l][k] : 0.f;
       g.x0 = cvt_flr(pix[0]);
       g.y0 = cvt_flr(pix[1]);
-      const col_f32x2 lo = {__builtin_amdgcn_fractf(pix[0]), __builtin_amdgcn_fractf(pix[1])};   // (lw, lh)
-      const col_f32x2 hi = col_f32x2{1.f, 1.f} - lo;                           // (hw, hh)
-      const col_f32x2 t = {hi[0] * wgt, lo[0] * wgt};                          // (hw, lw) * w
-      g.g12 = t * col_f32x2{hi[1], hi[1]};
-      g.g34 = t * col_f32x2{lo[1], lo[1]};
+      const float lw = __builtin_amdgcn_fractf(pix[0]), lh = __builtin_amdgcn_fractf(pix[1]);
+      const col_f32x2 ax = {1.f - lw, lw}, ay = {1.f - lh, lh};                // (hw, lw), (hh, lh): pairs as the packed ops take them
+      const col_f32x2 t = ax * col_f32x2{wgt, wgt};                            // (hw, lw) * w
+      g.g12 = t * col_f32x2{ay[0], ay[0]};
+      g.g34 = t * col_f32x2{ay[1], ay[1]};
       return g;
     };
 
@@ -512,7 +515,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
         ([&] {
           const Geo g = geometry(lc, std::integral_constant<int, Ks>{});
-          const unsigned a = g.gate ? (unsigned)(wbase[l] + __mul24(g.y0 - wy0[l], wwid[l]) + (g.x0 - wx0[l])) << 6 : 0u;
+          // pixel (x0, y0) sits at pool index woff + y0 * width + x0 (woff folds the window origin and base: one scalar)
+          const unsigned a = g.gate ? (unsigned)(__mul24(g.y0, wwid[l]) + g.x0 + woff[l]) << 6 : 0u;
           const unsigned rowb = g.gate ? (unsigned)wwid[l] << 6 : 0u;
           {
             col_f32x4 va[4], vb[4];
