@@ -305,6 +305,9 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
       }
     }
 
+    int woff[L];                                  // pixel (x0, y0) sits at pool index woff + y0 * width + x0
+#pragma unroll
+    for (int l = 0; l < L; ++l) woff[l] = wbase[l] - wy0[l] * wwid[l] - wx0[l];
     // (void * on purpose: with a _Float16 / __bf16 pointer here the host pass silently drops the kernel stubs)
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(const_cast<ST *>(value + rec_img * MD)), 0,
                                                         (int)((unsigned)S * (unsigned)MD * 2u), 0x00020000);
@@ -341,11 +344,11 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
       const float wgt = g.gate ? wts[l][k] : 0.f;
       g.x0 = cvt_flr(pix[0]);
       g.y0 = cvt_flr(pix[1]);
-      const col_f32x2 lo = {__builtin_amdgcn_fractf(pix[0]), __builtin_amdgcn_fractf(pix[1])};
-      const col_f32x2 hi = col_f32x2{1.f, 1.f} - lo;
-      const col_f32x2 t = {hi[0] * wgt, lo[0] * wgt};
-      g.g12 = t * col_f32x2{hi[1], hi[1]};
-      g.g34 = t * col_f32x2{lo[1], lo[1]};
+      const float lw = __builtin_amdgcn_fractf(pix[0]), lh = __builtin_amdgcn_fractf(pix[1]);
+      const col_f32x2 ax = {1.f - lw, lw}, ay = {1.f - lh, lh};
+      const col_f32x2 t = ax * col_f32x2{wgt, wgt};
+      g.g12 = t * col_f32x2{ay[0], ay[0]};
+      g.g34 = t * col_f32x2{ay[1], ay[1]};
       return g;
     };
     auto gather_level_lds = [&](auto lc) {
@@ -353,26 +356,39 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
       [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
         ([&] {
           const Geo g = geometry(lc, std::integral_constant<int, Ks>{});
-          const unsigned a = g.gate ? (unsigned)(wbase[l] + __mul24(g.y0 - wy0[l], wwid[l]) + (g.x0 - wx0[l])) << 5 : 0u;
+          const unsigned a = g.gate ? (unsigned)(__mul24(g.y0, wwid[l]) + g.x0 + woff[l]) << 5 : 0u;
           const unsigned rowb = g.gate ? (unsigned)wwid[l] << 5 : 0u;
-          col_f32x4 v1[2], v2[2], v3[2], v4[2];
+          // one pixel row (two corners, 4 x 16 B) in flight at a time: with all four corners the 5-level, 8-point
+          // instantiation spilled the next item's prefetched locations -- a wait for the load just issued, every item
+          {
+            col_f32x4 v1[2], v2[2];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const unsigned char *pa = pool + (a + rot[j]), *pb = pool + (a + rowb + rot[j]);
-            v1[j] = *reinterpret_cast<const col_f32x4 *>(pa);
-            v2[j] = *reinterpret_cast<const col_f32x4 *>(pa + PXB);
-            v3[j] = *reinterpret_cast<const col_f32x4 *>(pb);
-            v4[j] = *reinterpret_cast<const col_f32x4 *>(pb + PXB);
+            for (int j = 0; j < 2; ++j) {
+              const unsigned char *pa = pool + (a + rot[j]);
+              v1[j] = *reinterpret_cast<const col_f32x4 *>(pa);
+              v2[j] = *reinterpret_cast<const col_f32x4 *>(pa + PXB);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              fma_piece(j, v1[j], g.g12[0]);
+              fma_piece(j, v2[j], g.g12[1]);
+            }
           }
+          pin_acc();
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            col_f32x4 v3[2], v4[2];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            fma_piece(j, v1[j], g.g12[0]);
-            fma_piece(j, v2[j], g.g12[1]);
-          }
+            for (int j = 0; j < 2; ++j) {
+              const unsigned char *pb = pool + (a + rowb + rot[j]);
+              v3[j] = *reinterpret_cast<const col_f32x4 *>(pb);
+              v4[j] = *reinterpret_cast<const col_f32x4 *>(pb + PXB);
+            }
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            fma_piece(j, v3[j], g.g34[0]);
-            fma_piece(j, v4[j], g.g34[1]);
+            for (int j = 0; j < 2; ++j) {
+              fma_piece(j, v3[j], g.g34[0]);
+              fma_piece(j, v4[j], g.g34[1]);
+            }
           }
           pin_acc();
           __builtin_amdgcn_sched_barrier(0);
@@ -392,20 +408,33 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
           const unsigned a = (unsigned)(St[l] + g.y0 * W + g.x0) * MDb + (unsigned)(m * D) * 2u;
           const unsigned o1 = (top && lft) ? a : OOB, o2 = (top && rgt) ? a + MDb : OOB;
           const unsigned o3 = (bot && lft) ? a + (unsigned)W * MDb : OOB, o4 = (bot && rgt) ? a + (unsigned)W * MDb + MDb : OOB;
-          col_f32x4 v1[2], v2[2], v3[2], v4[2];
+          {
+            col_f32x4 v1[2], v2[2];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            v1[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o1 + rot[j]), 0, 0));
-            v2[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o2 + rot[j]), 0, 0));
-            v3[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o3 + rot[j]), 0, 0));
-            v4[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o4 + rot[j]), 0, 0));
+            for (int j = 0; j < 2; ++j) {
+              v1[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o1 + rot[j]), 0, 0));
+              v2[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o2 + rot[j]), 0, 0));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              fma_piece(j, v1[j], g.g12[0]);
+              fma_piece(j, v2[j], g.g12[1]);
+            }
           }
+          pin_acc();
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            col_f32x4 v3[2], v4[2];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            fma_piece(j, v1[j], g.g12[0]);
-            fma_piece(j, v2[j], g.g12[1]);
-            fma_piece(j, v3[j], g.g34[0]);
-            fma_piece(j, v4[j], g.g34[1]);
+            for (int j = 0; j < 2; ++j) {
+              v3[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o3 + rot[j]), 0, 0));
+              v4[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o4 + rot[j]), 0, 0));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              fma_piece(j, v3[j], g.g34[0]);
+              fma_piece(j, v4[j], g.g34[1]);
+            }
           }
           pin_acc();
           __builtin_amdgcn_sched_barrier(0);
