@@ -1,0 +1,12 @@
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+python3 $R/bench.py > $R/gpurun_out/r02_b_bench_distM.json 2> $R/gpurun_out/r02_b_bench_distM.err || echo bench failed
+python3 $R/bench.py --loc-dist I > $R/gpurun_out/r02_b_bench_distI.json 2> $R/gpurun_out/r02_b_bench_distI.err || echo benchI failed
+rm -rf $R/gpurun_out/stats_b
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_b -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/stats_b.log 2>&1 || echo stats failed
+find $R/gpurun_out/stats_b -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/r02_b_bench_kernel_stats_batch128_distM.csv \;
+find $R/gpurun_out/stats_b -name "*.csv" -size +1M -delete
+python3 $R/tools/bench_msda_op.py --shapes P2 --batches 8,32,128 --dists I,M,U --dtypes f32 > $R/gpurun_out/r02_op_col_P2_b.txt 2>/dev/null
+python3 $R/tools/bench_msda_op.py --shapes P3 --batches 1,4 --dists I,M,U --dtypes f16,bf16 > $R/gpurun_out/r02_op_col16_P3.txt 2>/dev/null
+python3 $R/tools/bench_msda_op.py --shapes P2 --batches 8,128 --dists I,M --dtypes f16,bf16 >> $R/gpurun_out/r02_op_col16_P3.txt 2>/dev/null
+python3 $R/tools/bench_msda_op.py --shapes P1,P4 --batches 8,128 --dists I,M --dtypes f32 >> $R/gpurun_out/r02_op_col_P2_b.txt 2>/dev/null
