@@ -34,6 +34,9 @@
 
 namespace pct {
 
+#ifndef PCT_COL_STORE_NT
+#define PCT_COL_STORE_NT 1
+#endif
 #ifndef PCT_COL_STREAM_NT
 #define PCT_COL_STREAM_NT 0   /* measured: nt on the record loads re-fetches the half lines two heads / two load groups share
                                 (I: 7.9 -> 9.7 GB read per launch, 1.95 -> 2.14 ms); kept as a build switch */
@@ -740,7 +743,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
         if (qo[s4] >= 0) {
           float *op = out + rec_img * M * D +
                       (size_t)((unsigned)(qo[s4] * M + m) * (unsigned)D + (unsigned)((((qi - s4) + (int)rho) & 3) * 4));
-          if (STREAM_NT) __builtin_nontemporal_store(w4[s4], reinterpret_cast<col_f32x4 *>(op));
+          if (STREAM_NT || PCT_COL_STORE_NT) __builtin_nontemporal_store(w4[s4], reinterpret_cast<col_f32x4 *>(op));
           else *reinterpret_cast<col_f32x4 *>(op) = w4[s4];
         }
       }
