@@ -203,7 +203,8 @@ def linear_add_layer_norm(x, linear, residual, norm):
     return out.view(residual.shape)
 
 
-_SPLIT_WS = {}                                   # (device, K) -> workspace the kernel refills with the split weights
+_SPLIT_WS = {}                # (device, stream, K) -> workspace the kernel refills with the split weights on every call:
+                              # one per stream, so launches on two streams never share it
 
 
 def linear_layer_norm_supported(x, linear, residual, norm):
@@ -230,7 +231,8 @@ def linear_layer_norm(x, linear, residual, norm):
         (linear.bias is None or linear.bias.data_ptr() % 16 == 0) and x2.stride(0) % 4 == 0 and r2.stride(0) % 4 == 0
     if not aligned:
         return add_layer_norm(residual, linear(x), norm)
-    key = (x.device, k)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    key = (x.device, stream, k)
     ws = _SPLIT_WS.get(key)
     if ws is None:
         ws = _SPLIT_WS[key] = torch.empty((3, 128, k), dtype=torch.bfloat16, device=x.device)
@@ -239,8 +241,7 @@ def linear_layer_norm(x, linear, residual, norm):
         rc = _lib.lib().pct_linear_add_layernorm_f32(
             x2.data_ptr(), x2.stride(0), k, linear.weight.data_ptr(), ws.data_ptr(),
             linear.bias.data_ptr() if linear.bias is not None else None, r2.data_ptr(), r2.stride(0),
-            norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps), rows, out.data_ptr(), 128,
-            torch.cuda.current_stream(x.device).cuda_stream)
+            norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps), rows, out.data_ptr(), 128, stream)
     _lib.check(rc, "linear_layer_norm")
     return out.view(residual.shape)
 
