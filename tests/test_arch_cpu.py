@@ -252,7 +252,7 @@ def test_reid_losses_batched_equal_the_per_item_loops():
             **c.loss_reid_mask({"pred_qd_mask": list(items_m)}, None, None, 1)}
     assert set(fast) == {"loss_reid_query", "loss_reid_query_aux", "loss_reid_mask"}
     for k in fast:
-        assert abs(float(fast[k]) - float(slow[k])) < 1e-5 * max(1.0, abs(float(slow[k]))), k
+        assert abs(float(fast[k].detach()) - float(slow[k].detach())) < 1e-5 * max(1.0, abs(float(slow[k].detach()))), k
     gf = torch.autograd.grad(sum(fast.values()), [output, masks], retain_graph=True)
     gs = torch.autograd.grad(sum(slow.values()), [output, masks])
     for a, b in zip(gf, gs):
