@@ -395,51 +395,73 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
         }(), ...);
       }(std::make_integer_sequence<int, PL>{});
     };
+    // A level whose box exceeds the pool, from global memory.  As in msda_forward_col.hip the fetches are shared so that
+    // a wave instruction touches whole pixels: here a head-pixel is 32 bytes, so the PAIR of lanes (2i, 2i + 1) works on
+    // one member's sample at a time -- corner offsets and weights broadcast by DPP, lane c fetches piece c of every corner
+    // (32 tag look-ups per instruction instead of 64) and accumulates "piece c of member s's sum"; after the level the
+    // pair exchanges the halves.  (With 8 points the two members are the two halves of one (query, head); with 4 points
+    // two neighbouring queries.)
     auto gather_level_global = [&](auto lc) {
       constexpr int l = decltype(lc)::value;
       const int H = Hs[l], W = Ws[l];
+      constexpr unsigned OOB = 0x80000000u;
+      const unsigned MDb = (unsigned)MD * 2u;
+      const unsigned pc = (unsigned)(lane & 1) << 4;                           // (an out-of-range offset stays out of range)
+      float part[2][8];                                                        // [member s][channel of piece lane & 1]
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[s2][e] = 0.f;
       [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
         ([&] {
           const Geo g = geometry(lc, std::integral_constant<int, Ks>{});
-          constexpr unsigned OOB = 0x80000000u;
           const bool top = g.gate && g.y0 >= 0, bot = g.gate && g.y0 + 1 <= H - 1;
           const bool lft = g.x0 >= 0, rgt = g.x0 + 1 <= W - 1;
-          const unsigned MDb = (unsigned)MD * 2u;
           const unsigned a = (unsigned)(St[l] + g.y0 * W + g.x0) * MDb + (unsigned)(m * D) * 2u;
           const unsigned o1 = (top && lft) ? a : OOB, o2 = (top && rgt) ? a + MDb : OOB;
           const unsigned o3 = (bot && lft) ? a + (unsigned)W * MDb : OOB, o4 = (bot && rgt) ? a + (unsigned)W * MDb + MDb : OOB;
-          {
-            col_f32x4 v1[2], v2[2];
+          [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
+            ([&] {
+              constexpr int CT = BcastCtrl<2, Ss>::value;
+              col_f32x4 v[4];
+              v[0] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(dpp_u<CT>(o1) + pc), 0, 0));
+              v[1] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(dpp_u<CT>(o2) + pc), 0, 0));
+              v[2] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(dpp_u<CT>(o3) + pc), 0, 0));
+              v[3] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(dpp_u<CT>(o4) + pc), 0, 0));
+              const float w[4] = {dpp_f<CT>(g.g12[0]), dpp_f<CT>(g.g12[1]), dpp_f<CT>(g.g34[0]), dpp_f<CT>(g.g34[1])};
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              v1[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o1 + rot[j]), 0, 0));
-              v2[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o2 + rot[j]), 0, 0));
-            }
+              for (int c4 = 0; c4 < 4; ++c4) {
+                const st8 hv = __builtin_bit_cast(st8, v[c4]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              fma_piece(j, v1[j], g.g12[0]);
-              fma_piece(j, v2[j], g.g12[1]);
-            }
-          }
-          pin_acc();
-          __builtin_amdgcn_sched_barrier(0);
-          {
-            col_f32x4 v3[2], v4[2];
+                for (int e = 0; e < 8; ++e) part[Ss][e] = fmaf(w[c4], Traits<T>::to_acc(hv[e]), part[Ss][e]);
+              }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              v3[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o3 + rot[j]), 0, 0));
-              v4[j] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(o4 + rot[j]), 0, 0));
-            }
+              for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              fma_piece(j, v3[j], g.g34[0]);
-              fma_piece(j, v4[j], g.g34[1]);
-            }
-          }
-          pin_acc();
-          __builtin_amdgcn_sched_barrier(0);
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(part[s2][e]));
+              __builtin_amdgcn_sched_barrier(0);
+            }(), ...);
+          }(std::make_integer_sequence<int, 2>{});
         }(), ...);
       }(std::make_integer_sequence<int, PL>{});
+      // lane i keeps piece i of its own sum (its part[i]) and receives piece i ^ 1 from its partner's part[i]
+      const bool odd = lane & 1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float own = odd ? part[1][e] : part[0][e];
+        const float t0 = dpp_f<0xB1>(part[0][e]), t1 = dpp_f<0xB1>(part[1][e]);  // quad_perm [1,0,3,2]: the partner's
+        const float other = odd ? t1 : t0;
+        if constexpr (HALVES == 2) {                                          // rho = lane & 1: slot 0 is piece i
+          acc[0][e] += own;
+          acc[1][e] += other;
+        } else {                                                               // slot j holds piece j ^ rho
+          const bool sw = (((unsigned)lane & 1u) ^ rho) != 0u;
+          acc[0][e] += sw ? other : own;
+          acc[1][e] += sw ? own : other;
+        }
+      }
+      pin_acc();
+      __builtin_amdgcn_sched_barrier(0);
     };
 
     auto stage_phase = [&](const int phx) {
