@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Upper bound on what an on-chip FFN (linear1 -> ReLU -> linear2 -> +residual -> LayerNorm without the [rows, 1024]
+hidden tensor in HBM) could gain: the two shipped kernels timed as they are, and with the hidden tensor's HBM traffic
+removed -- linear1 writing every row onto row 0 (output stride 0), linear2 reading row 0 for every row (input stride 0).
+Results are wrong by design; the instruction streams are unchanged.  Development tool."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pctrans_amd import _lib  # noqa: E402
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 128 * 21760
+lib = _lib.lib()
+dev = torch.device("cuda")
+g = torch.Generator(device=dev).manual_seed(0)
+x = torch.randn(rows, 128, device=dev, generator=g)
+w1 = torch.randn(1024, 128, device=dev, generator=g) * 0.05
+b1 = torch.randn(1024, device=dev, generator=g) * 0.1
+w2 = torch.randn(128, 1024, device=dev, generator=g) * 0.03
+b2 = torch.randn(128, device=dev, generator=g) * 0.1
+gamma, beta = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+h = torch.empty(rows, 1024, device=dev)
+out = torch.empty(rows, 128, device=dev)
+ws = torch.empty(3, 128, 1024, dtype=torch.bfloat16, device=dev)
+stream = torch.cuda.current_stream().cuda_stream
+
+
+def lin1(ldo):
+    _lib.check(lib.pct_linear_k128_f32(x.data_ptr(), 128, None, 0, 0, w1.data_ptr(), b1.data_ptr(), rows, 1024, 1,
+                                       h.data_ptr(), ldo, stream), "linear1")
+
+
+def lin2(ldx):
+    _lib.check(lib.pct_linear_add_layernorm_f32(h.data_ptr(), ldx, 1024, w2.data_ptr(), ws.data_ptr(), b2.data_ptr(),
+                                                x.data_ptr(), 128, gamma.data_ptr(), beta.data_ptr(), 1e-5, rows,
+                                                out.data_ptr(), 128, stream), "linear2")
+
+
+def timeit(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+lin1(1024)
+h.copy_(torch.relu(h))
+for name, fn in (("linear1 + ReLU, hidden written to HBM", lambda: lin1(1024)),
+                 ("linear1 + ReLU, every row written onto row 0", lambda: lin1(0)),
+                 ("linear2 + residual + LN, hidden read from HBM", lambda: lin2(1024)),
+                 ("linear2 + residual + LN, row 0 read for every row", lambda: lin2(0)),
+                 ("both, as shipped", lambda: (lin1(1024), lin2(1024))),
+                 ("both, without the hidden tensor's traffic", lambda: (lin1(0), lin2(0)))):
+    print("%-55s %7.3f ms" % (name, timeit(fn)), flush=True)
