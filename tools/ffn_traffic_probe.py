@@ -60,4 +60,24 @@ for name, fn in (("linear1 + ReLU, hidden written to HBM", lambda: lin1(1024)),
                  ("linear2 + residual + LN, row 0 read for every row", lambda: lin2(0)),
                  ("both, as shipped", lambda: (lin1(1024), lin2(1024))),
                  ("both, without the hidden tensor's traffic", lambda: (lin1(0), lin2(0)))):
-    print("%-55s %7.3f ms" % (name, timeit(fn)), flush=True)
+    try:
+        print("%-55s %7.3f ms" % (name, timeit(fn)), flush=True)
+    except RuntimeError:        # the shipped C ABI refuses a zero stride: these two need a build with that check relaxed
+        print("%-55s (needs a probe build of c_abi.hip accepting stride 0)" % name, flush=True)
+
+
+# ---- does the hidden tensor survive in the 256 MB memory-side cache if the FFN runs in row chunks? ---------------------
+def chunked(chunk):
+    for r0 in range(0, rows, chunk):
+        n = min(chunk, rows - r0)
+        _lib.check(lib.pct_linear_k128_f32(x[r0:].data_ptr(), 128, None, 0, 0, w1.data_ptr(), b1.data_ptr(), n, 1024, 1,
+                                           h.data_ptr(), 1024, stream), "linear1")
+        _lib.check(lib.pct_linear_add_layernorm_f32(h.data_ptr(), 1024, 1024, w2.data_ptr(), ws.data_ptr(), b2.data_ptr(),
+                                                    x[r0:].data_ptr(), 128, gamma.data_ptr(), beta.data_ptr(), 1e-5, n,
+                                                    out[r0:].data_ptr(), 128, stream), "linear2")
+
+
+if os.environ.get("PCT_PROBE_CHUNKS", "1") == "1":
+    for chunk in (8192, 16384, 32768, 65536, 131072, 262144):
+        print("linear1 -> linear2 in chunks of %6d rows (hidden chunk %4d MB, reused buffer)   %7.3f ms" % (
+            chunk, chunk * 4096 // 2 ** 20, timeit(lambda: chunked(chunk), iters=5)), flush=True)
