@@ -35,6 +35,9 @@ if ROOT not in sys.path:
 # find mode can settle on slow solvers (measured: 110.8 ms/step against 87.3 ms/step with the measured-best ones when
 # the 1x1 convolutions still went through it), so ask for a full find: it runs once per shape in the untimed pre-warm.
 os.environ.setdefault("MIOPEN_FIND_MODE", "1")
+# ... but keep MIOpen's naive reference solver out of that find: it is timed like every other candidate, 24 launches of
+# 0.38 s each at this batch (rocprofv3: naive_conv_ab_nonpacked_fwd_nhwc, 9 s of a 15 s run), and never wins
+os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
