@@ -293,8 +293,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
     // (opaque per iteration: the compiler otherwise hoists every per-lane expression of tid / qi out of the item loop --
     // a dozen 64-bit piece offsets, float copies of tid, ... -- and spills them)
     asm volatile("" : "+v"(tid), "+v"(qi));
-    const bool valid = qv >= 0;
-    const int q = valid ? qv : ~qv;
     const long long rec_img = (long long)b * S;
     int qs[4];
     quad_queries(qv, qs);
@@ -452,7 +450,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
     for (int l = 0; l < L; ++l) woff[l] = wbase[l] - wy0[l] * wwid[l] - wx0[l];
     float wts[L][P];
     stamp(2);
-    const float *vimg = value + rec_img * MD + m * D;                        // this image, this head
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value + (long long)b * S * MD), 0,
                                                         (int)((unsigned)S * (unsigned)MD * 4u), 0x00020000);
 
