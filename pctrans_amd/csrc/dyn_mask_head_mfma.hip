@@ -68,18 +68,27 @@ __global__ __launch_bounds__(DMM_BLOCK) void dmh_logits_mfma_kernel(const float 
   const int px_base = (pb * (DMM_BLOCK / 64) + wave) * (DMM_PT * 16);
 
   // ---- B operand of layer 0: feat[ch = 4g + j][px] for my pixel column of each tile (kept for all query pairs) ----
-  dm_s16x4 fb[DMM_PT];
-  float lx[DMM_PT], ly[DMM_PT];
+  // The relative-coordinate inputs  wx * (ref_x - loc_x) + wy * (ref_y - loc_y)  split into a per-query constant
+  // (folded into the bias, 8 FMAs per query pair instead of per pixel tile) and a per-pixel part that goes through the
+  // matrix core EXACTLY: a pixel coordinate (an integer below 2^16) is the sum of two bf16 pieces, a weight the sum of
+  // three, and the six products per axis fill 12 of the 16 k-slots of one more MFMA (k = 2 i + j: weight piece i times
+  // coordinate piece j; exact products, fp32 accumulation).  Was: 2 subtractions + 8 FMAs per lane and tile.
+  dm_s16x4 fb[DMM_PT], cb[DMM_PT];
   const float *fimg = feat + (size_t)n * C * HW;
   const float half = (float)(stride / 2);
 #pragma unroll
   for (int t = 0; t < DMM_PT; ++t) {
-    const int px = min(px_base + t * 16 + col, HW - 1);
+    const int px = min(px_base + col * DMM_PT + t, HW - 1);        // lane `col` owns DMM_PT CONSECUTIVE pixels (one 16-B store)
     const float *fp = fimg + (size_t)(4 * g) * HW + px;
     fb[t] = pack_bf16x4(fp[0], fp[(size_t)HW], fp[(size_t)2 * HW], fp[(size_t)3 * HW]);
-    const int y = px / W, x = px - y * W;
-    lx[t] = (float)(x * stride) + half;
-    ly[t] = (float)(y * stride) + half;
+    if constexpr (REL) {
+      const int y = px / W, x = px - y * W;
+      const float lxf = (float)(x * stride) + half, lyf = (float)(y * stride) + half;
+      const float xh = (float)(__bf16)lxf, yh = (float)(__bf16)lyf;
+      const float xl = lxf - xh, yl = lyf - yh;                  // exact, and exactly representable (integers < 2^16)
+      cb[t] = g == 0 ? pack_bf16x4(xh, xl, xh, xl) : g == 1 ? pack_bf16x4(xh, xl, yh, yl)
+            : g == 2 ? pack_bf16x4(yh, yl, yh, yl) : dm_s16x4{0, 0, 0, 0};
+    }
   }
 
   const int npairs = (Q + 1) / 2;
@@ -112,20 +121,26 @@ __global__ __launch_bounds__(DMM_BLOCK) void dmh_logits_mfma_kernel(const float 
       wyv[r] = REL ? pa[(r0 + r) * CIN + 1] : 0.f;
     }
     const float b2 = pa[OFF_B2];
-    float rx = 0.f, ry = 0.f;
+    dm_s16x4 ac = {0, 0, 0, 0};                                   // A operand of the coordinate MFMA: -(weight pieces)
     if constexpr (REL) {
-      rx = ref[((size_t)n * Q + q_acc) * 2] * (float)(W * stride);
-      ry = ref[((size_t)n * Q + q_acc) * 2 + 1] * (float)(H * stride);
+      const float rx = ref[((size_t)n * Q + q_acc) * 2] * (float)(W * stride);
+      const float ry = ref[((size_t)n * Q + q_acc) * 2 + 1] * (float)(H * stride);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b0v[r] = fmaf(wyv[r], ry, fmaf(wxv[r], rx, b0v[r]));
+      const float wxr = prw[hr * CIN + 0], wyr = prw[hr * CIN + 1];
+      const float x1 = (float)(__bf16)wxr, x2 = (float)(__bf16)(wxr - x1), x3 = (float)(__bf16)((wxr - x1) - x2);
+      const float y1 = (float)(__bf16)wyr, y2 = (float)(__bf16)(wyr - y1), y3 = (float)(__bf16)((wyr - y1) - y2);
+      ac = g == 0 ? pack_bf16x4(-x1, -x1, -x2, -x2) : g == 1 ? pack_bf16x4(-x3, -x3, -y1, -y1)
+         : g == 2 ? pack_bf16x4(-y2, -y2, -y3, -y3) : dm_s16x4{0, 0, 0, 0};
     }
     __bf16 *lrow = logits + ((size_t)n * Q + q_acc) * HW;
     const bool writer = (g & 1) == 0 && 2 * pr + (g >> 1) < Q;   // groups 0 / 2 hold the reduced logit of q0 / q1
 
+    float outv[DMM_PT];
 #pragma unroll
     for (int t = 0; t < DMM_PT; ++t) {
-      const float relx = rx - lx[t], rely = ry - ly[t];
-      dm_f32x4 c0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) c0[r] = fmaf(wyv[r], rely, fmaf(wxv[r], relx, b0v[r]));
+      dm_f32x4 c0 = {b0v[0], b0v[1], b0v[2], b0v[3]};
+      if constexpr (REL) c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ac, cb[t], c0, 0, 0, 0);
       c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, fb[t], c0, 0, 0, 0);
       // relu + bf16: accumulator rows 4g..4g+3 of pixel `col` == B operand k-slots 4g..4g+3 of column `col`
       const dm_s16x4 xb = pack_bf16x4(dm_relu(c0[0]), dm_relu(c0[1]), dm_relu(c0[2]), dm_relu(c0[3]));
@@ -135,8 +150,21 @@ __global__ __launch_bounds__(DMM_BLOCK) void dmh_logits_mfma_kernel(const float 
 #pragma unroll
       for (int r = 0; r < 4; ++r) part = fmaf(w2v[r], dm_relu(c1[r]), part);
       part += __shfl_xor(part, 16);                              // rows 4g..4g+3 (+) rows of the partner group
-      const int px = px_base + t * 16 + col;
-      if (writer && px < HW) lrow[px] = (__bf16)(part + b2);
+      outv[t] = part + b2;
+    }
+    if (writer) {                                                // the lane's 8 consecutive pixels: one 16-byte store
+      const int px0 = px_base + col * DMM_PT;
+      if (px0 + DMM_PT <= HW && ((HW & 7) == 0)) {
+        typedef __bf16 dm_bf16x8 __attribute__((ext_vector_type(8)));
+        dm_bf16x8 o;
+#pragma unroll
+        for (int t = 0; t < DMM_PT; ++t) o[t] = (__bf16)outv[t];
+        *reinterpret_cast<dm_bf16x8 *>(lrow + px0) = o;
+      } else {
+#pragma unroll
+        for (int t = 0; t < DMM_PT; ++t)
+          if (px0 + t < HW) lrow[px0 + t] = (__bf16)outv[t];
+      }
     }
   }
 }
