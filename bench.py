@@ -96,27 +96,29 @@ def model_like_offsets(head, feats, sigma_px=2.0):
     # bench steps only and per-kernel profiler averages are not diluted by these 2-image launches)
     from pctrans_amd import _lib
     _lib.lib().pct_msda_set_kernel_choice(3)
-    for i, lyr in enumerate(layers):          # layer by layer: rescaling layer i changes what layers > i see
-        cap = {}
-        attn = lyr.self_attn
-        orig = attn.forward
+    try:
+        for i, lyr in enumerate(layers):          # layer by layer: rescaling layer i changes what layers > i see
+            cap = {}
+            attn = lyr.self_attn
+            orig = attn.forward
 
-        def spy(query, *a, _orig=orig, _cap=cap, **kw):
-            qp = kw.get("_query_pos")
-            _cap["x"] = (query if qp is None else query + qp).detach()
-            return _orig(query, *a, **kw)
-        attn.forward = spy
-        try:
+            def spy(query, *a, _orig=orig, _cap=cap, **kw):
+                qp = kw.get("_query_pos")
+                _cap["x"] = (query if qp is None else query + qp).detach()
+                return _orig(query, *a, **kw)
+            attn.forward = spy
+            try:
+                with torch.no_grad():
+                    head.pixel_decoder.forward_features(small)
+            finally:
+                attn.forward = orig
+            off = F.linear(cap["x"].float(), attn.sampling_offsets.weight, attn.sampling_offsets.bias)
+            s = float(off.detach().std())
             with torch.no_grad():
-                head.pixel_decoder.forward_features(small)
-        finally:
-            attn.forward = orig
-        off = F.linear(cap["x"].float(), attn.sampling_offsets.weight, attn.sampling_offsets.bias)
-        s = float(off.detach().std())
-        with torch.no_grad():
-            attn.sampling_offsets.weight.mul_(sigma_px / s)
-        stds.append(float(F.linear(cap["x"].float(), attn.sampling_offsets.weight).std()))
-    _lib.lib().pct_msda_set_kernel_choice(-1)
+                attn.sampling_offsets.weight.mul_(sigma_px / s)
+            stds.append(float(F.linear(cap["x"].float(), attn.sampling_offsets.weight).std()))
+    finally:
+        _lib.lib().pct_msda_set_kernel_choice(-1)      # the process-wide override never outlives the calibration
     return stds
 
 
@@ -362,7 +364,11 @@ def main():
         S = sum(h * w for h, w in levels_hw)
         L, M, D, P = len(levels_hw), 8, 16, 4
         alg_bytes = args.batch * S * (2 * M * D * 4 + 3 * M * L * P * 4)
-        fwd = [ms for name, ms in launches if name == "forward"]
+        fwd = [rec[1] for rec in launches if rec[0] == "forward"]
+        kernels_run = sorted({rec[2] for rec in launches if rec[0] == "forward" and len(rec) > 2})
+        # the roofline record is about the pyramid-column kernel: every timed MSDeformAttn launch must have been it
+        assert kernels_run == [4], "timed MSDeformAttn launches ran kernels %s, expected the pyramid-column kernel" % (
+            [MSDA.KERNEL_NAMES.get(k, k) for k in kernels_run],)
         mean_ms = sum(fwd) / max(1, len(fwd))
         achieved = alg_bytes / (mean_ms * 1e-3) / 1e9 if fwd else None
         out = {
@@ -388,8 +394,9 @@ def main():
                 "queries": args.queries, "parallelism": "dp%d (images sharded, no data-path collective)" % world,
             },
             "roofline": {
-                "kernel": "pct::msda_forward_col_kernel<L,fused,256> (MSDeformAttn forward incl. softmax + location math; "
-                          "pyramid-column LDS gather, one lane per (query, head))",
+                "kernel": "%s: pct::msda_forward_col_kernel<L=%d, fused front-end, 256 threads> (MSDeformAttn forward incl. "
+                          "softmax + location math; LDS gather, one lane per (query, head)); id reported by "
+                          "pct_msda_last_kernel() after every timed launch" % (MSDA.KERNEL_NAMES[kernels_run[0]], L),
                 "location_dist": ({"name": "M", "definition": "sampling_offsets.weight ~ N(0, s), zero bias, s scaled per "
                                    "encoder layer so that offsets are N(0, 2 px) on the sampled level",
                                    "offset_std_px_per_layer": offset_std} if args.loc_dist == "M" else
@@ -402,7 +409,7 @@ def main():
             },
         }
         # second hand-written kernel on the path, MFMA-bound: the FFN's linear1 (+ ReLU) on linear_k128.hip
-        ffn1 = [ms for name, ms in launches if name == "linear_k128 n=1024 relu"]
+        ffn1 = [rec[1] for rec in launches if rec[0] == "linear_k128 n=1024 relu"]
         if ffn1:
             rows = args.batch * S
             ms1 = sum(ffn1) / len(ffn1)

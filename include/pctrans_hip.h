@@ -24,9 +24,10 @@
  *   - work is enqueued on `stream` (a hipStream_t, may be NULL = default stream); no host sync.
  *   - return value: 0 on success; >0 = a hipError_t from the launch; <0 = one of PCT_ERR_* below.
  *     Unlike the reference (which only printf()s launch errors, cuh:953-957) errors are returned.
- *   - `im2col_step` keeps the reference's precondition batch % min(batch, im2col_step) == 0 (cu:55-57);
- *     the whole batch is still processed by ONE launch (chunking was a CUDA-grid-size workaround and
- *     does not change results).
+ *   - `im2col_step` keeps the reference's precondition batch % min(batch, im2col_step) == 0 (cu:55-57) and is
+ *     otherwise unused: a batch is ONE launch unless its value tensor reaches 2 GiB (32-bit byte offsets inside a
+ *     launch); such a batch is sent out in chunks of whole images on the same kernel and stream, as the reference
+ *     does with im2col_step (cu:66-80).  Chunking does not change results.
  */
 #ifndef PCTRANS_HIP_H_
 #define PCTRANS_HIP_H_

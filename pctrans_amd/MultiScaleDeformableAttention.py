@@ -67,6 +67,14 @@ def _stream(t):
 
 from ._timing import kernel_timing, timed as _timed  # noqa: E402,F401  (bench.py's roofline leg)
 
+KERNEL_NAMES = {0: "none", 1: "windowed (msda_forward_win.hip)", 2: "generic (msda_forward.hip)",
+                3: "quad-owner (msda_forward_dpp.hip)", 4: "pyramid-column (msda_forward_col.hip / msda_forward_col16.hip)"}
+
+
+def _last_kernel():
+    """Kernel id of the forward launch just enqueued by THIS thread's call (pct_msda_last_kernel, include/pctrans_hip.h)."""
+    return int(_lib.lib().pct_msda_last_kernel())
+
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
     """-> Tensor[N, Lq, M*D].  fp32/fp64 as the reference; fp16/bf16 value with fp32 loc/weights is new capability
@@ -82,7 +90,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     if attn_weight.dtype != aux:
         attn_weight = attn_weight.to(aux)
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
-    with torch.cuda.device(value.device), _timed("forward", value):
+    with torch.cuda.device(value.device), _timed("forward", value, _last_kernel):
         rc = getattr(_lib.lib(), _FWD[value.dtype])(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
             attn_weight.data_ptr(), N, S, M, D, L, Lq, P, int(im2col_step), out.data_ptr(), _stream(value))
@@ -153,7 +161,7 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, refer
         ref = ref.contiguous()
         batch_stride = Lq * L * 2
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
-    with torch.cuda.device(value.device), _timed("forward", value):
+    with torch.cuda.device(value.device), _timed("forward", value, _last_kernel):
         rc = _lib.lib().pct_ms_deform_attn_fused_forward_f32(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), ref.data_ptr(), batch_stride,
             sampling_offsets.data_ptr(), attention_logits.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(),

@@ -37,6 +37,12 @@ namespace pct {
 #ifndef PCT_COL_STORE_NT
 #define PCT_COL_STORE_NT 1
 #endif
+#ifndef PCT_COL_LOC_NT
+#define PCT_COL_LOC_NT 0      /* experiment: nt on the location records only (whole lines, one reader) */
+#endif
+#ifndef PCT_COL_KO_NOCONF
+#define PCT_COL_KO_NOCONF 0   /* knock-out (WRONG RESULTS, timing only): LDS gather addresses forced conflict-free */
+#endif
 #ifndef PCT_COL_STREAM_NT
 #define PCT_COL_STREAM_NT 0   /* measured: nt on the record loads re-fetches the half lines two heads / two load groups share
                                 (I: 7.9 -> 9.7 GB read per launch, 1.95 -> 2.14 ms); kept as a build switch */
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       int pi = g * 4 + ((s4 - qi) & 3);
       if (NPL % 4 != 0 && pi >= NPL) pi = g * 4;                               // (a partial last group: harmless repeat)
       const unsigned r = (unsigned)((qs[s4] < 0 ? ~qs[s4] : qs[s4]) * M + m_);
-      raw[g][s4] = STREAM_NT ? __builtin_nontemporal_load(reinterpret_cast<const col_f32x4 *>(
+      raw[g][s4] = (STREAM_NT || PCT_COL_LOC_NT) ? __builtin_nontemporal_load(reinterpret_cast<const col_f32x4 *>(
                                    base + (size_t)(r * (unsigned)(L * P * 2) + (unsigned)(pi * 4))))
                              : *reinterpret_cast<const col_f32x4 *>(base + (size_t)(r * (unsigned)(L * P * 2) + (unsigned)(pi * 4)));
     }
@@ -516,7 +522,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
         ([&] {
           const Geo g = geometry(lc, std::integral_constant<int, Ks>{});
           // pixel (x0, y0) sits at pool index woff + y0 * width + x0 (woff folds the window origin and base: one scalar)
+#if PCT_COL_KO_NOCONF
+          const unsigned a = g.gate ? (unsigned)(((__mul24(g.y0, wwid[l]) + g.x0 + woff[l]) & ~3) | (lane & 3)) << 6 : 0u;
+#else
           const unsigned a = g.gate ? (unsigned)(__mul24(g.y0, wwid[l]) + g.x0 + woff[l]) << 6 : 0u;
+#endif
           const unsigned rowb = g.gate ? (unsigned)wwid[l] << 6 : 0u;
           {
             col_f32x4 va[4], vb[4];

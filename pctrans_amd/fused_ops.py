@@ -92,9 +92,6 @@ def linear_k128(x, weight, bias=None, relu=False, x_add=None):
     return out.view(*x.shape[:-1], n)
 
 
-_PAD32 = {}                                      # id(conv) -> (weight version, bias version, w32, b32)
-
-
 def conv1x1_from_token_rows_supported(x, conv):
     """A 1x1 convolution of 128 channels-last feature maps with at most 32 output channels, forward only, small batch:
     the decoder's `mask_head` (dec.py:539) on the pixel decoder's finest map, which is a transposed VIEW of the encoder's
@@ -118,19 +115,23 @@ def conv1x1_from_token_rows(x, conv):
     bit; fp32-accurate where autocast would have rounded the operands to bf16."""
     N, _, H, W = x.shape
     co = conv.out_channels
-    key = id(conv)
-    bv = conv.bias._version if conv.bias is not None else -1
-    ent = _PAD32.get(key)
-    if ent is None or ent[0] != conv.weight._version or ent[1] != bv or ent[2].device != x.device:
+    # the padded copies live ON the module (a plain attribute, not a buffer: the state dict is unchanged), so they can
+    # never be taken for another module's -- a process-wide table keyed on id(conv) could, once a freed module's id is
+    # handed to a new one -- and they are rebuilt whenever a parameter was written in place (version counter), replaced
+    # or moved (storage pointer, device)
+    w, b = conv.weight, conv.bias
+    stamp = (w._version, w.data_ptr(), b._version if b is not None else -1, b.data_ptr() if b is not None else 0,
+             x.device)
+    ent = conv.__dict__.get("_pct_pad32")
+    if ent is None or ent[0] != stamp:
         w32 = torch.zeros((32, 128), dtype=torch.float32, device=x.device)
-        w32[:co] = conv.weight.detach().reshape(co, 128)
+        w32[:co] = w.detach().reshape(co, 128)
         b32 = torch.zeros((32,), dtype=torch.float32, device=x.device)
-        if conv.bias is not None:
-            b32[:co] = conv.bias.detach()
-        if len(_PAD32) > 64:
-            _PAD32.clear()
-        ent = _PAD32[key] = (conv.weight._version, bv, w32, b32)
-    outs = [linear_k128(x[n].permute(1, 2, 0).reshape(H * W, 128), ent[2], ent[3]) for n in range(N)]   # views: no copy
+        if b is not None:
+            b32[:co] = b.detach()
+        ent = (stamp, w32, b32)
+        conv.__dict__["_pct_pad32"] = ent
+    outs = [linear_k128(x[n].permute(1, 2, 0).reshape(H * W, 128), ent[1], ent[2]) for n in range(N)]   # views: no copy
     y = torch.stack(outs, 0)                                               # [N, HW, 32]
     return y[..., :co].permute(0, 2, 1).reshape(N, co, H, W).contiguous()
 

@@ -22,7 +22,6 @@ from .... import fused_ops
 from ..functions import MSDeformAttnFunction, ms_deform_attn_core_pytorch
 
 _ALLOW_CPU_REFERENCE = False
-_CHECKED_SHAPES = set()
 
 
 def allow_cpu_reference(flag=True):
@@ -108,13 +107,15 @@ class MSDeformAttn(nn.Module):
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         # the reference's check (ops/modules/ms_deform_attn.py:95) compares on the device and therefore blocks the host on
-        # every call; a given shapes tensor is checked once (keyed on storage + version), then trusted
-        key = (input_spatial_shapes.data_ptr(), input_spatial_shapes._version, input_spatial_shapes.device, Len_in)
-        if key not in _CHECKED_SHAPES:
+        # every call; a given shapes TENSOR OBJECT is checked once and the verdict is kept on that object together with
+        # its version counter: a new tensor (even one that re-uses a freed allocation) or an in-place write is re-checked
+        stamp = (input_spatial_shapes._version, Len_in)
+        if getattr(input_spatial_shapes, "_pct_shapes_checked", None) != stamp:
             assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
-            if len(_CHECKED_SHAPES) > 64:
-                _CHECKED_SHAPES.clear()
-            _CHECKED_SHAPES.add(key)
+            try:
+                input_spatial_shapes._pct_shapes_checked = stamp
+            except (AttributeError, RuntimeError):      # (a tensor subclass without a __dict__: checked every call)
+                pass
 
         # encoder self-attention: the three input projections read the same rows (query is input_flatten): one launch
         merged = None

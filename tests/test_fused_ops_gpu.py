@@ -544,3 +544,44 @@ def test_loss_and_postprocessing_definitions_on_the_device(golden):
             np.testing.assert_array_equal(got_l, want_l)
             for lab in (0, 1):
                 np.testing.assert_allclose(np.sort(got_c[got_l == lab]), np.sort(want_c[want_l == lab]), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_token_row_conv_never_serves_another_modules_weights():
+    """The 1x1 `mask_head` projection at batch <= 4 keeps padded copies of its weights.  They live on the module, so a
+    second module (evaluation sweeps, a new checkpoint) built after the first one was freed -- CPython may hand it the
+    same id(), and init bumps the version counters identically -- gets its own; in-place writes and replaced parameters
+    are followed."""
+    import gc
+    from pctrans_amd import fused_ops
+    from pctrans_amd.layers import Conv2d
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    rows = torch.randn(2, 64 * 64, 128, generator=g).to(dev)
+    x = rows.view(2, 64, 64, 128).permute(0, 3, 1, 2)                      # the encoder's token rows seen as NCHW
+    outs = []
+    for seed in (1, 2, 3, 4, 5):
+        torch.manual_seed(seed)
+        conv = Conv2d(128, 16, kernel_size=1).to(dev)
+        with torch.no_grad():
+            assert fused_ops.conv1x1_from_token_rows_supported(x, conv)
+            got = fused_ops.conv1x1_from_token_rows(x, conv)
+            want = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double())
+        assert float((got.double() - want).abs().max()) < 2e-5, "seed %d: stale weights?" % seed
+        outs.append(got)
+        del conv
+        gc.collect()
+    assert not torch.equal(outs[0], outs[1])
+    # in-place update and parameter replacement on ONE module
+    torch.manual_seed(9)
+    conv = Conv2d(128, 16, kernel_size=1).to(dev)
+    with torch.no_grad():
+        a = fused_ops.conv1x1_from_token_rows(x, conv)
+        conv.weight.mul_(2.0)
+        b = fused_ops.conv1x1_from_token_rows(x, conv)
+        conv.weight = torch.nn.Parameter(conv.weight.detach().clone() * 0.5)
+        c = fused_ops.conv1x1_from_token_rows(x, conv)
+        conv.weight.data.mul_(3.0)            # a .data write does not bump the version: documented limit of every cache here
+    bias = conv.bias.view(1, -1, 1, 1)
+    assert float(((b - bias) - 2.0 * (a - bias)).abs().max()) < 1e-4
+    assert float((c - a).abs().max()) < 1e-4
