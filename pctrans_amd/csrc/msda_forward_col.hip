@@ -40,8 +40,25 @@ namespace pct {
 #ifndef PCT_COL_LOC_NT
 #define PCT_COL_LOC_NT 0      /* experiment: nt on the location records only (whole lines, one reader) */
 #endif
+#ifndef PCT_COL_W_NT
+#define PCT_COL_W_NT 0
+#endif
+#ifndef PCT_COL_KO_NOSTAGE
+#define PCT_COL_KO_NOSTAGE 0  /* knock-out (WRONG RESULTS, timing only): no window staging (LDS-DMA) at all */
+#endif
+#ifndef PCT_COL_KO_NOGATHER
+#define PCT_COL_KO_NOGATHER 0 /* knock-out (WRONG RESULTS, timing only): 1 = no LDS reads + FMAs in the gather, 2 = no gather at all */
+#endif
 #ifndef PCT_COL_KO_NOCONF
 #define PCT_COL_KO_NOCONF 0   /* knock-out (WRONG RESULTS, timing only): LDS gather addresses forced conflict-free */
+#endif
+#ifndef PCT_COL_ORDER
+#define PCT_COL_ORDER 1       /* gather order of the levels: 0 = finest .. coarsest, 1 = finest, coarsest, then the rest */
+#endif
+#ifndef PCT_COL_LOC_AT
+#define PCT_COL_LOC_AT 0      /* the gather step behind which the next item's location record is fetched, all groups at once (the
+                                 two 64-byte halves of a 128-byte line back to back: -2 % on I and M against one group
+                                 per gathered level, same-box A/B) */
 #endif
 #ifndef PCT_COL_STREAM_NT
 #define PCT_COL_STREAM_NT 0   /* measured: nt on the record loads re-fetches the half lines two heads / two load groups share
@@ -85,6 +102,17 @@ __device__ __forceinline__ void quad_transpose_in(col_f32x4 (&x)[4], const bool 
   x[3] = quad_rot<3>(x[3]);
 }
 
+// Gather order of the levels (step ll -> level).  The finest level (the last one in PCTrans' pyramids) comes first; its
+// window is the largest, and the level that most often still fits beside it in the pool is the COARSEST one, so that
+// one goes second and the two middle levels share the next phase: with model-like offsets at the north-star shape
+// {finest, coarsest} + {the two middle levels} is two phases where finest-to-coarsest order needed three for every
+// fifth item (each phase costs a re-staging of the pool and two barriers).
+template <int L>
+__host__ __device__ constexpr int col_level_of_step(const int ll)
+{
+  return PCT_COL_ORDER == 0 ? L - 1 - ll : (ll == 0 ? L - 1 : (ll == 1 ? 0 : L - ll));
+}
+
 template <int L, bool FUSED, int BLOCK, bool STAMP = false>
 __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) void msda_forward_col_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
@@ -97,7 +125,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
   // neighbouring columns and the sibling head re-use) out of the XCD's L2
   constexpr bool STREAM_NT = PCT_COL_STREAM_NT;
   // diagnostic build only (STAMP): per-phase cycle sums of wave 0, written to a buffer nothing else reads
-  unsigned long long t_prev = 0, t_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = 0, t_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   auto stamp = [&](int phase) {
     if constexpr (STAMP) {
       __builtin_amdgcn_sched_barrier(0);
@@ -121,15 +149,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
 
   // ---- level geometry (uniform) -------------------------------------------------------------------------------------
   int Hs[L], Ws[L], St[L];
-  float fH[L], fW[L];
   col_f32x2 fWH[L], invWH[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     Hs[l] = (int)shapes[2 * l];
     Ws[l] = (int)shapes[2 * l + 1];
     St[l] = (int)starts[l];
-    fH[l] = uni((float)Hs[l]);
-    fW[l] = uni((float)Ws[l]);
     fWH[l] = uni_pair((float)Ws[l], (float)Hs[l]);
     invWH[l] = uni_pair(1.0f / (float)Ws[l], 1.0f / (float)Hs[l]);           // FUSED: offset / (W, H) as offset * (1 / W, 1 / H)
   }
@@ -164,16 +189,64 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       else break;                                                              // (L pixels per column: cannot exceed BLOCK)
     }
   }
-  const int ncol = CX * CY;
+
+  // ---- this lane's SLOT in a column (fixed for the whole launch).  A column's queries are dealt to the lanes level by
+  // level, finest (last) first, each level taking a block of mx * my lanes where mx x my is its LARGEST cell over the
+  // grid -- the grid search above made these blocks fit the workgroup -- so a lane's (level, x, y inside the cell) never
+  // changes from item to item and the per-item decode is two table look-ups and a multiply-add (it used to walk the
+  // levels: ~100 vector and ~250 scalar instructions per item).  A lane whose slot lies outside a smaller border cell
+  // idles for that item.
+  int lane_c0 = 0;                                                             // level start + (y * W + x) inside the cell
+  unsigned lane_slot = 0x000FFFFFu;                                            // x | y << 10 | level << 20; x = y = 1023: no slot
+  {
+    int r = tid;
+    bool placed = false;
+#pragma unroll
+    for (int ll = 0; ll < L; ++ll) {
+      const int l = L - 1 - ll;
+      int mx = 0, my = 0;
+      for (int c = 0; c < CX; ++c) mx = max(mx, col_lo(c + 1, Ws[l], CX) - col_lo(c, Ws[l], CX));
+      for (int c = 0; c < CY; ++c) my = max(my, col_lo(c + 1, Hs[l], CY) - col_lo(c, Hs[l], CY));
+      const int cnt = mx * my;                                                 // (<= BLOCK <= 1024: x, y fit 10 bits)
+      if (!placed && r < cnt) {
+        const int ly = r / max(mx, 1), lx = r - ly * max(mx, 1);
+        lane_slot = (unsigned)lx | ((unsigned)ly << 10) | ((unsigned)l << 20);
+        lane_c0 = St[l] + ly * Ws[l] + lx;
+        placed = true;
+      }
+      r -= placed ? 0 : cnt;
+    }
+  }
+  // cell tables in LDS, carved off the end of the pool: xtab[l][cx] = first x | width << 16, ytab[l][cy] likewise, then
+  // the level widths.  A grid whose tables would take more than half the pool (absurdly elongated maps: thousands of
+  // columns along one axis) is not used at all: the launch then runs on FLAT columns, see the decode.
+  const int tab_px = ((L * (CX + CY) + L) * 4 + PXB - 1) / PXB;
+  const int pool_eff = pool_px - tab_px;
+  unsigned *tab = reinterpret_cast<unsigned *>(pool + (size_t)max(pool_eff, 0) * PXB);
+  const bool use_tab = pool_eff * 2 >= pool_px;
+  if (use_tab) {
+    for (int t = tid; t < L * CX; t += BLOCK) {
+      const int l = t / CX, c = t - l * CX;
+      const int a = col_lo(c, Ws[l], CX);
+      tab[t] = (unsigned)a | ((unsigned)(col_lo(c + 1, Ws[l], CX) - a) << 16);
+    }
+    for (int t = tid; t < L * CY; t += BLOCK) {
+      const int l = t / CY, c = t - l * CY;
+      const int a = col_lo(c, Hs[l], CY);
+      tab[L * CX + t] = (unsigned)a | ((unsigned)(col_lo(c + 1, Hs[l], CY) - a) << 16);
+    }
+    if (tid < L) tab[L * (CX + CY) + tid] = (unsigned)Ws[tid];
+    __syncthreads();
+  }
+  const int pool_use = use_tab ? pool_eff : pool_px;                           // pixels the windows may take
+  int ncol = CX * CY;
+  if (!use_tab) {
+    ncol = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) ncol += (Hs[l] * Ws[l] + BLOCK - 1) / BLOCK;
+  }
   const int items = N * ncol * M;
   const UDiv dv_ncolM = make_udiv(ncol * M), dv_2ncol = make_udiv(2 * ncol), dv_CX = make_udiv(CX);
-  const UDiv dv_2CX = make_udiv(2 * CX), dv_2CY = make_udiv(2 * CY);
-  auto col_lo_f = [&](const int c, const int W, const int C, const UDiv dv_2C) {   // == col_lo(c, W, C), scalar unit
-    return udiv_s(2 * c * W + C - 1, dv_2C);
-  };
-
-  // pixels 0 and 1 of the pool are zeros: gated-out samples read them (weight 0 times a guaranteed-finite value)
-  if (tid < 8) reinterpret_cast<col_f32x4 *>(pool)[tid] = col_f32x4{0.f, 0.f, 0.f, 0.f};
 
   // this lane's place in its quad (quad-cooperative record access, above)
   int qi = lane & 3;
@@ -222,63 +295,85 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       m_ = M - 1;
     }
     const int cy = udiv_s(col, dv_CX), cx = col - cy * CX;
-    int q = 0, r = tid, q_first = 0;
-    bool found = false, have_first = false;
+    int q;
+    bool valid;
+    if (use_tab) {
+      const unsigned lx = lane_slot & 0x3FFu, ly = (lane_slot >> 10) & 0x3FFu, lv = lane_slot >> 20;
+      const unsigned char *tb = reinterpret_cast<const unsigned char *>(tab);
+      const unsigned xt = *reinterpret_cast<const unsigned *>(tb + (__umul24(lv, (unsigned)(CX * 4)) + (unsigned)(cx * 4)));
+      const unsigned yt = *reinterpret_cast<const unsigned *>(tb + (__umul24(lv, (unsigned)(CY * 4)) + (unsigned)((L * CX + cy) * 4)));
+      const unsigned lw = *reinterpret_cast<const unsigned *>(tb + (lv * 4u + (unsigned)(L * (CX + CY) * 4)));
+      valid = lx < (xt >> 16) && ly < (yt >> 16);
+      q = lane_c0 + (int)__umul24(yt & 0xFFFFu, lw) + (int)(xt & 0xFFFFu);
+    } else {
+      // flat columns: BLOCK consecutive queries of one level (no tables, no divisions; the boxes of such a strip are wide,
+      // so its levels mostly take the global-memory path -- correct, not fast)
+      int c = col;
+      q = 0;
+      valid = false;
 #pragma unroll
-    for (int ll = 0; ll < L; ++ll) {
-      const int l = L - 1 - ll;                                               // finest level (last in PCTrans) first
-      const int xa = col_lo_f(cx, Ws[l], CX, dv_2CX), nx = col_lo_f(cx + 1, Ws[l], CX, dv_2CX) - xa;
-      const int ya = col_lo_f(cy, Hs[l], CY, dv_2CY), ny = col_lo_f(cy + 1, Hs[l], CY, dv_2CY) - ya;
-      const int cnt = nx * ny;
-      if (!have_first && cnt > 0) { have_first = true; q_first = St[l] + ya * Ws[l] + xa; }
-      const bool in = !found && r < cnt;
-      if (in) {
-        const int ly = (int)(((float)r + 0.5f) * uni(1.0f / (float)max(nx, 1)));
-        const int lx = r - ly * nx;
-        q = St[l] + (ya + ly) * Ws[l] + xa + lx;
-        found = true;
+      for (int l = 0; l < L; ++l) {
+        const int cnt = Hs[l] * Ws[l], nch = (cnt + BLOCK - 1) / BLOCK;
+        if (c >= 0 && c < nch) {
+          q = St[l] + c * BLOCK + tid;
+          valid = c * BLOCK + tid < cnt;
+        }
+        c = c >= nch ? c - nch : -1;
       }
-      r -= found ? 0 : cnt;
     }
-    qv_ = found ? q : ~q_first;            // idle lanes shadow a query of the column: they cannot move its boxes
+    // idle lanes shadow a query of the column (they cannot move its boxes): the wave's first busy lane's; a wave without
+    // any busy lane shadows query 0 (correct, merely wide boxes; it takes a pyramid whose levels shrink the wrong way)
+    const unsigned long long vm = __ballot(valid);
+    const int q_sh = vm ? __builtin_amdgcn_readlane(q, (int)__builtin_ctzll(vm)) : 0;
+    qv_ = valid ? q : ~q_sh;
   };
-  // the four queries of this lane's quad (record s of the quad belongs to lane 4 * (lane / 4) + s)
-  auto quad_queries = [&](const int qv_, int (&qs)[4]) {
-    qs[0] = dpp_i<0x00>(qv_);
-    qs[1] = dpp_i<0x55>(qv_);
-    qs[2] = dpp_i<0xAA>(qv_);
-    qs[3] = dpp_i<0xFF>(qv_);
+  // ---- quad-cooperative record access (see the top of the file) through per-image buffer descriptors: a scalar base, one
+  // 32-bit vector offset per record and the piece as an immediate -- no 64-bit vector address arithmetic.  A lane forms
+  // the byte offset of ITS OWN record once; the quad's other three get it by DPP (record s of the quad belongs to lane
+  // 4 * (lane / 4) + s).  Offsets past the end of a descriptor read zeros / drop the store: an idle lane's record is
+  // simply moved out of range for the store.  (launcher: S < 2^24, per-image tensors below 2 GiB)
+  typedef unsigned col_u32x4 __attribute__((ext_vector_type(4)));
+  auto rec_index = [&](const int qv_, const int m_) {                         // query * M + head of the lane's own record
+    return __umul24((unsigned)(qv_ ^ (qv_ >> 31)), (unsigned)M) + (unsigned)m_;
   };
-  // group g (64 bytes) of the location records of the quad's four queries.  Per-image base pointers are uniform and the
-  // offsets 32-bit (launcher: a per-image tensor stays below 4 GiB), so the loads take the scalar-base + vector-offset
-  // form instead of 64-bit vector address arithmetic.
-  auto issue_loc_group = [&](auto gc, const int b_, const int m_, const int qv_, col_f32x4 (&raw)[NGL][4]) {
-    constexpr int g = decltype(gc)::value;
-    int qs[4];
-    quad_queries(qv_, qs);
-    const float *base = loc + (long long)b_ * S * M * (L * P * 2);
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      int pi = g * 4 + ((s4 - qi) & 3);
-      if (NPL % 4 != 0 && pi >= NPL) pi = g * 4;                               // (a partial last group: harmless repeat)
-      const unsigned r = (unsigned)((qs[s4] < 0 ? ~qs[s4] : qs[s4]) * M + m_);
-      raw[g][s4] = (STREAM_NT || PCT_COL_LOC_NT) ? __builtin_nontemporal_load(reinterpret_cast<const col_f32x4 *>(
-                                   base + (size_t)(r * (unsigned)(L * P * 2) + (unsigned)(pi * 4))))
-                             : *reinterpret_cast<const col_f32x4 *>(base + (size_t)(r * (unsigned)(L * P * 2) + (unsigned)(pi * 4)));
-    }
+  auto quad_offsets = [&](const unsigned own_bytes, unsigned (&off)[4]) {     // + the piece this lane fetches of record s
+    off[0] = dpp_u<0x00>(own_bytes) + ((unsigned)((0 - qi) & 3) << 4);
+    off[1] = dpp_u<0x55>(own_bytes) + ((unsigned)((1 - qi) & 3) << 4);
+    off[2] = dpp_u<0xAA>(own_bytes) + ((unsigned)((2 - qi) & 3) << 4);
+    off[3] = dpp_u<0xFF>(own_bytes) + ((unsigned)((3 - qi) & 3) << 4);
   };
+  constexpr int RSRC_FLAGS = 0x00020000;
+  // the location records of the quad's four queries, all groups (64 bytes each) at once: the two halves of a 128-byte line
+  // are requested back to back
   auto issue_loc = [&](const int b_, const int m_, const int qv_, col_f32x4 (&raw)[NGL][4]) {
-    [&]<int... Gs>(std::integer_sequence<int, Gs...>) {
-      (issue_loc_group(std::integral_constant<int, Gs>{}, b_, m_, qv_, raw), ...);
-    }(std::make_integer_sequence<int, NGL>{});
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(loc + (long long)b_ * S * M * (L * P * 2)), 0,
+                                                      (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 8)), RSRC_FLAGS);
+    unsigned off[4];
+    quad_offsets(rec_index(qv_, m_) * (unsigned)(L * P * 8), off);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int g = 0; g < NGL; ++g)                // (a partial last group reads into the next record: never looked at)
+        raw[g][s4] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off[s4] + g * 64), 0, PCT_COL_LOC_NT ? 2 : 0));
   };
   // FUSED: the query's reference points (one (x, y) per level), fetched with the record
   auto issue_ref = [&](const int b_, const int qv_, col_f32x2 (&rr)[L]) {
     if constexpr (FUSED) {
-      const float *rrow = ref + b_ * ref_batch_stride;
-      const unsigned o = (unsigned)(qv_ < 0 ? ~qv_ : qv_) * (unsigned)(L * 2);
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ref + b_ * ref_batch_stride), 0,
+                                                        (int)((unsigned)S * (unsigned)(L * 8)), RSRC_FLAGS);
+      const unsigned o = (unsigned)(qv_ ^ (qv_ >> 31)) * (unsigned)(L * 8);
+      if constexpr (L % 2 == 0) {                   // 16-byte loads (launcher: ref is 16-byte aligned when L is even)
 #pragma unroll
-      for (int l = 0; l < L; ++l) rr[l] = *reinterpret_cast<const col_f32x2 *>(rrow + (size_t)(o + 2u * l));
+        for (int l = 0; l < L; l += 2) {
+          const col_f32x4 r4 = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(o + 8u * l), 0, 0));
+          rr[l] = col_f32x2{r4[0], r4[1]};
+          rr[l + 1] = col_f32x2{r4[2], r4[3]};
+        }
+      } else {
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+          rr[l] = __builtin_bit_cast(col_f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(o + 8u * l), 0, 0));
+      }
     }
   };
 
@@ -298,10 +393,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
   while (have) {
     // (opaque per iteration: the compiler otherwise hoists every per-lane expression of tid / qi out of the item loop --
     // a dozen 64-bit piece offsets, float copies of tid, ... -- and spills them)
-    asm volatile("" : "+v"(tid), "+v"(qi));
-    const long long rec_img = (long long)b * S;
-    int qs[4];
-    quad_queries(qv, qs);
+    asm volatile("" : "+v"(tid), "+v"(qi), "+v"(lane_slot), "+v"(lane_c0));
+    const unsigned own = rec_index(qv, m);                                    // this lane's record: query * M + head
 
     // FUSED: the reference points sit in L2 (shared by the heads and the batch): fetched here, not a whole item ahead
     // (eight more registers alive across the gather spilled); the transposition below runs while they arrive
@@ -321,16 +414,28 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
           if constexpr (FUSED) v = __builtin_elementwise_fma(v, invWH[l], rr[l]);
           // from here on the PIXEL coordinates (w_im, h_im) = loc * (W, H) - 0.5 (cuh:283-288), formed once for the
           // boxes and the gather (packed FMAs: x and y in one instruction)
-          lxy[l][k] = __builtin_elementwise_fma(v, fWH[l], col_f32x2{-0.5f, -0.5f});
+          const col_f32x2 px = __builtin_elementwise_fma(v, fWH[l], col_f32x2{-0.5f, -0.5f});
+          // The reference gates a sample on -1 < w_im < W and -1 < h_im < H (cuh:290-296).  Here the gate is folded into
+          // the coordinate itself: a coordinate that fails its test (NaN included: the comparison is false) moves to -2,
+          // one that passes W moves to W.  The staged window carries a ZERO APRON of two pixels on each side (columns
+          // -2, -1 and W, W + 1), so a sample moved there reads four apron pixels -- its contribution is exactly 0 and no
+          // map pixel is touched, which is what the reference's `if` gives -- and every other sample keeps its own
+          // coordinates.  No per-sample gate, select or predicate is left in the gather (it cost 13 vector instructions
+          // per sample).
+          lxy[l][k][0] = fminf(px[0] > -1.f ? px[0] : -2.f, fWH[l][0]);
+          lxy[l][k][1] = fminf(px[1] > -1.f ? px[1] : -2.f, fWH[l][1]);
         }
     }
 
     // (everything that waits for the reference-point loads must be complete before the atomic below is issued)
+    if constexpr (FUSED) {
 #pragma unroll
-    for (int l = 0; l < L; ++l)
+      for (int l = 0; l < L; ++l)
 #pragma unroll
-      for (int k = 0; k < P; ++k) asm volatile("" : "+v"(lxy[l][k]));
+        for (int k = 0; k < P; ++k) asm volatile("" : "+v"(lxy[l][k]));
+    }
     __builtin_amdgcn_sched_barrier(0);
+    stamp(7);                                                                 // records waited for, transposed, lxy formed
     // ---- publish the next item's index, fetch the one after it (its value is parked in LDS behind the staging barrier).
     // Issued behind the loads the pre-pass waits for: the memory counter is in-order, a wait for those would include it. ---
     unsigned f_new = 0u;
@@ -360,21 +465,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
     // ---- pre-pass: per-level bounding box (first corners, biased by +1; the box covers x0 .. x0 + 1) ----------------
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-      // min / max over the lane's four samples on the raw pixel coordinates, then ONE clamp per lane and level (a clamp
-      // is monotone, so it commutes with min / max; v_min / v_max return the other operand for a NaN, so a NaN sample --
-      // gated out anyway -- drops out).  A sample is gated in iff -1 < w_im < W: clamping to [-1, W - 0.5] maps a
-      // gated-out coordinate onto one a gated-in sample could have, so it can only widen the box towards the map
-      // border, never past the 1-pixel apron.  The gather floors the very same registers.
-      const float mnx = __builtin_amdgcn_fmed3f(fminf(fminf(lxy[l][0][0], lxy[l][1][0]), fminf(lxy[l][2][0], lxy[l][3][0])),
-                                                -1.f, uni(fW[l] - 0.5f));
-      const float mxx = __builtin_amdgcn_fmed3f(fmaxf(fmaxf(lxy[l][0][0], lxy[l][1][0]), fmaxf(lxy[l][2][0], lxy[l][3][0])),
-                                                -1.f, uni(fW[l] - 0.5f));
-      const float mny = __builtin_amdgcn_fmed3f(fminf(fminf(lxy[l][0][1], lxy[l][1][1]), fminf(lxy[l][2][1], lxy[l][3][1])),
-                                                -1.f, uni(fH[l] - 0.5f));
-      const float mxy = __builtin_amdgcn_fmed3f(fmaxf(fmaxf(lxy[l][0][1], lxy[l][1][1]), fmaxf(lxy[l][2][1], lxy[l][3][1])),
-                                                -1.f, uni(fH[l] - 0.5f));
-      const unsigned lo = (unsigned)(cvt_flr(mnx) + 1) | ((unsigned)(cvt_flr(mny) + 1) << 16);
-      const unsigned hi = (unsigned)(cvt_flr(mxx) + 2) | ((unsigned)(cvt_flr(mxy) + 2) << 16);
+      // min / max over the lane's four samples (already inside [-2, W] x [-2, H], see above); the gather floors the very
+      // same registers.  Packed as u16 pairs biased by +2 (low corner) / +3 (high corner + 1: the box covers x0 .. x0 + 1).
+      const float mnx = fminf(fminf(lxy[l][0][0], lxy[l][1][0]), fminf(lxy[l][2][0], lxy[l][3][0]));
+      const float mxx = fmaxf(fmaxf(lxy[l][0][0], lxy[l][1][0]), fmaxf(lxy[l][2][0], lxy[l][3][0]));
+      const float mny = fminf(fminf(lxy[l][0][1], lxy[l][1][1]), fminf(lxy[l][2][1], lxy[l][3][1]));
+      const float mxy = fmaxf(fmaxf(lxy[l][0][1], lxy[l][1][1]), fmaxf(lxy[l][2][1], lxy[l][3][1]));
+      const unsigned lo = (unsigned)(cvt_flr(mnx) + 2) | ((unsigned)(cvt_flr(mny) + 2) << 16);
+      const unsigned hi = (unsigned)(cvt_flr(mxx) + 3) | ((unsigned)(cvt_flr(mxy) + 3) << 16);
       const unsigned red = wave_reduce_box(lo, hi);                 // lane 31: min lo, lane 63: ~max hi
       if ((lane & 31) == 31) bb[(l * NW + wave) * 2 + (lane >> 5)] = red;
     }
@@ -382,18 +480,15 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
     // anything that waits on the memory counter there -- it is in-order -- would otherwise wait for these loads too.) ---------
     col_f32x4 wraw[NGW][4];
     {
-      const float *wbase_img = attn + rec_img * M * (L * P);
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(attn + (long long)b * S * M * (L * P)), 0,
+                                                        (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 4)), RSRC_FLAGS);
+      unsigned off[4];
+      quad_offsets(own * (unsigned)(L * P * 4), off);
 #pragma unroll
-      for (int g = 0; g < NGW; ++g)
+      for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          int pi = g * 4 + ((s4 - qi) & 3);
-          if (L % 4 != 0 && pi >= L) pi = g * 4;
-          const unsigned r = (unsigned)((qs[s4] < 0 ? ~qs[s4] : qs[s4]) * M + m);
-          wraw[g][s4] = STREAM_NT ? __builtin_nontemporal_load(reinterpret_cast<const col_f32x4 *>(
-                                        wbase_img + (size_t)(r * (unsigned)(L * P) + (unsigned)(pi * 4))))
-                                  : *reinterpret_cast<const col_f32x4 *>(wbase_img + (size_t)(r * (unsigned)(L * P) + (unsigned)(pi * 4)));
-        }
+        for (int g = 0; g < NGW; ++g)
+          wraw[g][s4] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off[s4] + g * 64), 0, PCT_COL_W_NT ? 2 : 0));
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // boxes in LDS before the barrier
     stamp(0);
@@ -416,29 +511,29 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       for (int l = 0; l < L; ++l) {
         unsigned lo, hi;
         block_box<NW>(bb + l * NW * 2, lo, hi);
-        const int x0 = (int)(lo & 0xFFFFu) - 1, y0 = (int)(lo >> 16) - 1;    // un-bias: origin may be -1 (apron)
-        const int x1 = (int)(hi & 0xFFFFu) - 1, y1 = (int)(hi >> 16) - 1;
-        const bool empty = x0 > x1 || y0 > y1;
-        wx0[l] = x0;
-        wy0[l] = y0;
-        wwid[l] = empty ? 1 : x1 - x0 + 1;
-        whgt[l] = empty ? 0 : y1 - y0 + 1;
+        // un-bias (the origin may be -2: apron).  hi >= lo + 1 in both halves -- a box always holds a sample's two
+        // columns and two rows -- so there is no empty case
+        const unsigned lx = lo & 0xFFFFu, ly = lo >> 16;
+        wx0[l] = (int)lx - 2;
+        wy0[l] = (int)ly - 2;
+        wwid[l] = (int)((hi & 0xFFFFu) - lx) + 1;
+        whgt[l] = (int)((hi >> 16) - ly) + 1;
         wsize[l] = wwid[l] * whgt[l];
       }
-      // levels are gathered in a fixed order, finest (last) first; a level that does not fit beside the ones already
+      // levels are gathered in a fixed order (col_level_of_step); a level that does not fit beside the ones already
       // planned opens a new PHASE: the pool is re-staged right before it (two barriers)
       int ph = 0, used = 0;
       bool fresh = true;
 #pragma unroll
       for (int ll = 0; ll < L; ++ll) {
-        const int l = L - 1 - ll;
+        const int l = col_level_of_step<L>(ll);
         starts_phase[l] = false;
-        if (wsize[l] > pool_px - 2) {                                          // never fits: gathered from global memory
+        if (wsize[l] > pool_use) {                                             // never fits: gathered from global memory
           phase_of[l] = -1;
           wbase[l] = 0;
           continue;
         }
-        if (used + wsize[l] > pool_px - 2) {
+        if (used + wsize[l] > pool_use) {
           ++ph;
           used = 0;
           fresh = true;
@@ -446,7 +541,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
         phase_of[l] = ph;
         starts_phase[l] = fresh;
         fresh = false;
-        wbase[l] = used + 2;                                                   // pixels 0, 1 are the zero pixels
+        wbase[l] = used;
         used += wsize[l];
       }
     }
@@ -483,29 +578,24 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
         for (int e = 0; e < 2; ++e)
           acc[j][e] = __builtin_elementwise_fma(wwb, col_f32x2{vb[j][2 * e], vb[j][2 * e + 1]}, acc[j][e]);
     };
-    // a sample's geometry: gate (cuh:290-296), first corner, the four bilinear * attention weights
+    // a sample's geometry: first corner and the four bilinear * attention weights (the gate of cuh:290-296 is already in
+    // the coordinates, see where lxy is formed)
     struct Geo {
       col_f32x2 g12, g34;                 // (hh * hw, hh * lw) * w and (lh * hw, lh * lw) * w
       int x0, y0;
-      bool gate;
     };
     auto geometry = [&](auto lc, auto kc) {
       constexpr int l = decltype(lc)::value;
       constexpr int k = decltype(kc)::value;
       // (opaque: without it the compiler hoists every sample's geometry to the top of the item and keeps it alive)
-      col_f32x2 pix = lxy[l][k];
-      asm volatile("" : "+v"(pix));
+      asm volatile("" : "+v"(lxy[l][k]));                                      // (in place: the coordinates are not needed again)
+      const col_f32x2 pix = lxy[l][k];
       Geo g;
-      g.gate = pix[1] > -1 && pix[0] > -1 && pix[1] < fH[l] && pix[0] < fW[l];    // false for NaN
-      // a gated-out sample (possibly Inf / NaN coordinates) becomes pixel (0, 0) with weight 0, reading the zero pixels
-      pix[0] = g.gate ? pix[0] : 0.f;
-      pix[1] = g.gate ? pix[1] : 0.f;
-      const float wgt = g.gate ? wts[l][k] : 0.f;
       g.x0 = cvt_flr(pix[0]);
       g.y0 = cvt_flr(pix[1]);
       const float lw = __builtin_amdgcn_fractf(pix[0]), lh = __builtin_amdgcn_fractf(pix[1]);
       const col_f32x2 ax = {1.f - lw, lw}, ay = {1.f - lh, lh};                // (hw, lw), (hh, lh): pairs as the packed ops take them
-      const col_f32x2 t = ax * col_f32x2{wgt, wgt};                            // (hw, lw) * w
+      const col_f32x2 t = ax * col_f32x2{wts[l][k], wts[l][k]};                // (hw, lw) * w
       g.g12 = t * col_f32x2{ay[0], ay[0]};
       g.g34 = t * col_f32x2{ay[1], ay[1]};
       return g;
@@ -514,8 +604,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
     // One level from its LDS window, one pixel ROW of a sample at a time (two corners = 8 x 16 B per lane in flight): the
     // other waves of the SIMD cover the LDS latency.  (A rolling pipeline with the next row's reads in flight during the
     // FMAs needs 32 more data registers than the 168 of three workgroups per CU leave: it spilled and was slower.)
-    // All four corners lie inside the staged window (out-of-map ones are zeros); a gated-out sample reads the two zero
-    // pixels (offset 0, row step 0).
+    // All four corners lie inside the staged window (out-of-map ones are apron zeros).
     auto gather_level_lds = [&](auto lc) {
       constexpr int l = decltype(lc)::value;
       [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
@@ -523,11 +612,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
           const Geo g = geometry(lc, std::integral_constant<int, Ks>{});
           // pixel (x0, y0) sits at pool index woff + y0 * width + x0 (woff folds the window origin and base: one scalar)
 #if PCT_COL_KO_NOCONF
-          const unsigned a = g.gate ? (unsigned)(((__mul24(g.y0, wwid[l]) + g.x0 + woff[l]) & ~3) | (lane & 3)) << 6 : 0u;
+          const unsigned a = (unsigned)(((__mul24(g.y0, wwid[l]) + g.x0 + woff[l]) & ~3) | (lane & 3)) << 6;
 #else
-          const unsigned a = g.gate ? (unsigned)(__mul24(g.y0, wwid[l]) + g.x0 + woff[l]) << 6 : 0u;
+          const unsigned a = (unsigned)(__mul24(g.y0, wwid[l]) + g.x0 + woff[l]) << 6;
 #endif
-          const unsigned rowb = g.gate ? (unsigned)wwid[l] << 6 : 0u;
+          const unsigned rowb = (unsigned)wwid[l] << 6;
           {
             col_f32x4 va[4], vb[4];
 #pragma unroll
@@ -579,8 +668,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
         ([&] {
           const Geo g = geometry(lc, std::integral_constant<int, Ks>{});
-          const bool top = g.gate && g.y0 >= 0, bot = g.gate && g.y0 + 1 <= H - 1;
-          const bool lft = g.x0 >= 0, rgt = g.x0 + 1 <= W - 1;
+          const bool top = (unsigned)g.y0 < (unsigned)H, bot = (unsigned)(g.y0 + 1) < (unsigned)H;   // (y0, x0 in [-2, H] x [-2, W])
+          const bool lft = (unsigned)g.x0 < (unsigned)W, rgt = (unsigned)(g.x0 + 1) < (unsigned)W;
           const unsigned a = (unsigned)(St[l] + g.y0 * W + g.x0) * MDb + (unsigned)(m * D) * 4u;
           const unsigned o1 = (top && lft) ? a : OOB, o2 = (top && rgt) ? a + MDb : OOB;
           const unsigned o3 = (bot && lft) ? a + (unsigned)W * MDb : OOB, o4 = (bot && rgt) ? a + (unsigned)W * MDb + MDb : OOB;
@@ -650,6 +739,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
               for (int r = wv; r < whgt[l]; r += NW) {
                 const int y = wy0[l] + r;
                 const bool in_y = (unsigned)y < (unsigned)Hs[l];
+                if (PCT_COL_KO_NOSTAGE) continue;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     rsrc, (__attribute__((address_space(3))) void *)(dst + (size_t)(r * wwid[l] + c0) * PXB), 16,
                     (int)(in_y ? voff : OOB), (int)(in_y ? lvl_off + (unsigned)y * row_bytes : 0u), 0, 0);
@@ -667,33 +757,47 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
 #pragma unroll
         for (int k = 0; k < P; ++k) wts[l][k] = wraw[l / 4][l & 3][k];
       if constexpr (FUSED) {                                                  // softmax over the record's L * P logits
+        // exp(x - mx) as exp2(x * log2(e) - mx * log2(e)): one packed FMA per logit pair instead of a subtraction and a
+        // multiplication per logit; sums and the final scaling packed as well; 1 / sum as v_rcp_f32 (1 ulp) instead of
+        // the ten-instruction IEEE division -- 50 vector instructions instead of 98 per (query, head)
+        static_assert(P % 2 == 0, "logit pairs");
         float mx = -INFINITY;
 #pragma unroll
         for (int l = 0; l < L; ++l)
 #pragma unroll
           for (int k = 0; k < P; ++k) mx = fmaxf(mx, wts[l][k]);
-        float sum = 0.f;
+        constexpr float LOG2E = 1.44269504088896340736f;
+        const float nm = -mx * LOG2E;
+        col_f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
         for (int l = 0; l < L; ++l)
 #pragma unroll
-          for (int k = 0; k < P; ++k) {
-            wts[l][k] = __expf(wts[l][k] - mx);
-            sum += wts[l][k];
+          for (int k = 0; k < P; k += 2) {
+            const col_f32x2 a = __builtin_elementwise_fma(col_f32x2{wts[l][k], wts[l][k + 1]}, col_f32x2{LOG2E, LOG2E},
+                                                          col_f32x2{nm, nm});
+            wts[l][k] = __builtin_amdgcn_exp2f(a[0]);
+            wts[l][k + 1] = __builtin_amdgcn_exp2f(a[1]);
+            sum2 += col_f32x2{wts[l][k], wts[l][k + 1]};
           }
-        const float inv = 1.f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum2[0] + sum2[1]);
 #pragma unroll
         for (int l = 0; l < L; ++l)
 #pragma unroll
-          for (int k = 0; k < P; ++k) wts[l][k] *= inv;
+          for (int k = 0; k < P; k += 2) {
+            const col_f32x2 w2 = col_f32x2{wts[l][k], wts[l][k + 1]} * col_f32x2{inv, inv};
+            wts[l][k] = w2[0];
+            wts[l][k + 1] = w2[1];
+          }
       }
     };
 
     auto level_step = [&](auto llc) {
       constexpr int ll = decltype(llc)::value;
-      constexpr int l = L - 1 - ll;
+      constexpr int l = col_level_of_step<L>(ll);
       if (starts_phase[l]) {
         if (ll > 0) __syncthreads();                                          // every wave is done with the pool
         stage_phase(phase_of[l]);
+        if (ll == 0) stamp(8);                                                // first phase's LDS-DMA issued
         if constexpr (ll == 0) {
           if (have_n) decode(item_n, b_n, m_n, qv_n);                          // while the LDS-DMA pieces are in flight
         }
@@ -709,12 +813,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
           next_idx[1] = f_new;
         }
         front_end();
+        stamp(9);                                                             // weights waited for, transposed (FUSED: soft-max)
       }
-      if (phase_of[l] >= 0) gather_level_lds(std::integral_constant<int, l>{});
+      if (PCT_COL_KO_NOGATHER == 2) {
+      } else if (phase_of[l] >= 0) gather_level_lds(std::integral_constant<int, l>{});
       else gather_level_global(std::integral_constant<int, l>{});             // box larger than the pool: global memory
+      // (marking the global-memory path unlikely makes hipcc outline it behind a real call: 544 bytes of scratch per lane, 10x slower)
+      if (ll == 0) stamp(10);                                                 // first level gathered
       // one group of the next item's location record per level: its registers are the ones this level's points freed
-      if constexpr (ll < NGL) {
-        if (have_n) issue_loc_group(std::integral_constant<int, ll>{}, b_n, m_n, qv_n, raw);
+      // the next item's location record (32 registers: the ones this level's points and the weights freed)
+      if constexpr (ll == (PCT_COL_LOC_AT < L ? PCT_COL_LOC_AT : L - 1)) {
+        if (have_n) issue_loc(b_n, m_n, qv_n, raw);
       }
 
     };
@@ -743,17 +852,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       // slot s <- received register (i - s) % 4: reverse the order (compile time), then rotate by (-i) % 4
       col_f32x4 w4[4] = {u[0], u[3], u[2], u[1]};
       rot_regs(w4, qi0, qn1);
-      int qo[4];
-      quad_queries(qv, qo);
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(out + (long long)b * S * MD, 0,
+                                                        (int)((unsigned)S * (unsigned)MD * 4u), RSRC_FLAGS);
+      // an idle lane's record goes out of range (the descriptor's bounds check drops the store)
+      // (the record index is formed again rather than kept alive through the gather)
+      const unsigned own_o = (rec_index(qv, m) * (unsigned)(D * 4)) | ((unsigned)(qv >> 31) & 0x80000000u);
+      const unsigned oo[4] = {dpp_u<0x00>(own_o), dpp_u<0x55>(own_o), dpp_u<0xAA>(own_o), dpp_u<0xFF>(own_o)};
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        if (qo[s4] >= 0) {
-          float *op = out + rec_img * M * D +
-                      (size_t)((unsigned)(qo[s4] * M + m) * (unsigned)D + (unsigned)((((qi - s4) + (int)rho) & 3) * 4));
-          if (STREAM_NT || PCT_COL_STORE_NT) __builtin_nontemporal_store(w4[s4], reinterpret_cast<col_f32x4 *>(op));
-          else *reinterpret_cast<col_f32x4 *>(op) = w4[s4];
-        }
-      }
+      for (int s4 = 0; s4 < 4; ++s4)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(col_u32x4, w4[s4]), rs,
+                                               (int)(oo[s4] + ((unsigned)(((qi - s4) + (int)rho) & 3) << 4)), 0,
+                                               (STREAM_NT || PCT_COL_STORE_NT) ? 2 : 0);
     }
 
     item = item_n;
@@ -765,7 +874,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
   }
   if constexpr (STAMP) {
     if (tid == 0 && stamps)
-      for (int i = 0; i < 8; ++i) stamps[(size_t)blockIdx.x * 8 + i] = t_sum[i];
+      for (int i = 0; i < 16; ++i) stamps[(size_t)blockIdx.x * 16 + i] = t_sum[i];
   }
 }
 
@@ -778,10 +887,13 @@ int launch_msda_forward_col(const void *value, const int64_t *shapes, const int6
                             hipStream_t stream, const float *ref, long long ref_batch_stride)
 {
   if ((((uintptr_t)value | (uintptr_t)out | (uintptr_t)loc | (uintptr_t)attn) & 15u)) return -100;
-  if (ref && (((uintptr_t)ref) & 7u)) return -100;
+  if (ref && (((uintptr_t)ref) & ((L % 2 == 0) ? 15u : 7u))) return -100;
+  if (ref && (L % 2 == 0) && (ref_batch_stride & 3)) return -100;
   if (D != 16 || P != 4 || L < 3 || L > 5 || Lq != S || M < 1) return -100;
   if ((long long)N * ((long long)S + 4096) * M >= 0x7fffffffLL) return -100;   // item / record arithmetic headroom
-  if ((long long)S * M * L * P * 8 >= 0xffffffffLL) return -100;               // 32-bit byte offsets inside an image
+  if ((long long)S * M * L * P * 8 >= 0x7fffffffLL) return -100;               // 32-bit byte offsets inside an image, all tensors
+  if ((long long)S * M * D * 4 >= 0x7fffffffLL) return -100;                   // (0x80000000 is the out-of-range sentinel)
+  if (S >= (1 << 24) || M >= (1 << 16)) return -100;                           // 24-bit multiplies in the record index
   // threads per workgroup x workgroups per CU: 1024 x 1 (~150 KB pool, 128 registers), 512 x 2 (~75 KB each, 128 registers),
   // 384 x 2 (~75 KB, 168 registers), 256 x 3 (~50 KB, 168 registers).  With more than one workgroup per CU the memory
   // phases of one (records, staging) overlap the gather of the others.

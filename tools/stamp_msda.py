@@ -18,7 +18,7 @@ dist = sys.argv[1] if len(sys.argv) > 1 else "I"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 shapes, P = SHAPES["P2"]
 v, sh, st, loc, w = make(shapes, P, N, dist, torch.float32)
-buf = torch.zeros(1024 * 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(1024 * 16, dtype=torch.int64, device="cuda")
 lib = ctypes.CDLL(_lib.LIB_PATH)
 lib.pct_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
 MSDA.ms_deform_attn_forward(v, sh, st, loc, w, 128)
@@ -27,16 +27,19 @@ lib.pct_debug_set_stamp_buffer(buf.data_ptr())
 MSDA.ms_deform_attn_forward(v, sh, st, loc, w, 128)
 torch.cuda.synchronize()
 lib.pct_debug_set_stamp_buffer(None)
-t = buf.view(1024, 8).double().cpu()
 kern = _lib.lib().pct_msda_last_kernel()
-if kern == 4:   # pyramid-column kernel
+if kern == 4:   # pyramid-column kernel: 16 slots per workgroup, in program order
+    t = buf.view(1024, 16).double().cpu()
     t = t[t.sum(1) > 0]
-    names = ["decode + record loads + boxes", "barrier A (boxes)", "windows + weight loads issued", "staging issue",
-             "staging barrier (DMA landed)", "gather (all phases)", "store + next item", "-"]
+    order = [(7, "records waited for + transposed, pixel coordinates"), (0, "queue + box pre-pass + weight loads issued"),
+             (1, "barrier A (boxes)"), (2, "windows / phases planned"), (8, "first phase: LDS-DMA issued"),
+             (3, "next item decoded"), (4, "staging barrier (DMA landed)"), (9, "weights transposed (fused: soft-max)"),
+             (10, "first level gathered"), (5, "other levels (incl. later phases)"), (6, "store + hand-over")]
 else:
-    names = ["first prepass", "barrier A (boxes, pool free)", "windows", "staging issue", "barrier B (staged)", "gather+store",
-             "next item's prepass", "-"]
+    t = buf.view(2048, 8)[:1024].double().cpu()
+    order = list(enumerate(["first prepass", "barrier A (boxes, pool free)", "windows", "staging issue", "barrier B (staged)",
+                            "gather+store", "next item's prepass"]))
 tot = t.sum(1).mean().item()
 print("dist=%s N=%d  mean cycles per WG %.0f" % (dist, N, tot))
-for i, n in enumerate(names[:7]):
-    print("  %-30s %6.1f %%   %10.0f cyc/WG" % (n, 100 * t[:, i].mean().item() / tot, t[:, i].mean().item()))
+for i, n in order:
+    print("  %-52s %6.1f %%   %10.0f cyc/WG" % (n, 100 * t[:, i].mean().item() / tot, t[:, i].mean().item()))
