@@ -43,6 +43,18 @@ namespace pct {
 #ifndef PCT_COL_W_NT
 #define PCT_COL_W_NT 0
 #endif
+#ifndef PCT_COL_KO_NOLOC
+#define PCT_COL_KO_NOLOC 0    /* knock-out (WRONG RESULTS, timing only): 1 = the location records are not loaded, 2 = nor the weights */
+#endif
+#ifndef PCT_COL_KO_NOSTORE
+#define PCT_COL_KO_NOSTORE 0  /* knock-out (WRONG RESULTS, timing only): no output stores */
+#endif
+#ifndef PCT_COL_W_LATE
+#define PCT_COL_W_LATE 0      /* experiment: the odd head of a pair fetches its weights later (no effect on traffic or time) */
+#endif
+#ifndef PCT_COL_ITEM_ORDER
+#define PCT_COL_ITEM_ORDER 0
+#endif
 #ifndef PCT_COL_KO_NOSTAGE
 #define PCT_COL_KO_NOSTAGE 0  /* knock-out (WRONG RESULTS, timing only): no window staging (LDS-DMA) at all */
 #endif
@@ -285,7 +297,15 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
     b_ = udiv_s(it, dv_ncolM);
     const int r_img = it - b_ * (ncol * M);
     int col;
-    if (r_img < 2 * ncol * (M >> 1)) {
+    if (PCT_COL_ITEM_ORDER == 1 && M == 8) {                                   // (experiment) column outermost, the 8 heads adjacent
+      col = r_img >> 3;
+      m_ = r_img & 7;
+    } else if (PCT_COL_ITEM_ORDER == 2 && M == 8) {                            // (experiment) two pairs, then column, then 4 heads
+      const int pg = udiv_s(r_img, make_udiv(4 * ncol));
+      const int rr = r_img - pg * 4 * ncol;
+      col = rr >> 2;
+      m_ = 4 * pg + (rr & 3);
+    } else if (r_img < 2 * ncol * (M >> 1)) {
       const int pr = udiv_s(r_img, dv_2ncol);
       const int rr = r_img - pr * 2 * ncol;
       col = rr >> 1;
@@ -350,6 +370,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
                                                       (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 8)), RSRC_FLAGS);
     unsigned off[4];
     quad_offsets(rec_index(qv_, m_) * (unsigned)(L * P * 8), off);
+    if (PCT_COL_KO_NOLOC == 1 || PCT_COL_KO_NOLOC == 2) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int g = 0; g < NGL; ++g) raw[g][s4] = col_f32x4{(float)off[s4], 0.3f, 0.4f, 0.6f};
+      return;
+    }
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
@@ -479,7 +506,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
     // ---- this item's weights (FUSED: logits): fetched now, looked at after the staging barrier.  (Behind the pre-pass:
     // anything that waits on the memory counter there -- it is in-order -- would otherwise wait for these loads too.) ---------
     col_f32x4 wraw[NGW][4];
-    {
+    auto load_weights = [&]() {
       const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(attn + (long long)b * S * M * (L * P)), 0,
                                                         (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 4)), RSRC_FLAGS);
       unsigned off[4];
@@ -488,8 +515,15 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
         for (int g = 0; g < NGW; ++g)
-          wraw[g][s4] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off[s4] + g * 64), 0, PCT_COL_W_NT ? 2 : 0));
-    }
+          wraw[g][s4] = (PCT_COL_KO_NOLOC == 2 || PCT_COL_KO_NOLOC == 3) ? col_f32x4{(float)off[s4], 0.1f, 0.2f, 0.3f} :
+              __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off[s4] + g * 64), 0, PCT_COL_W_NT ? 2 : 0));
+    };
+    // A weight record is 64 bytes: HALF a 128-byte line, the other half being the sibling head's, which the neighbouring
+    // workgroup fetches at about the same moment -- and two misses on one line in flight together are two fills on the
+    // memory side (measured: the weights came in 1.75x (I) / 2.08x (M) over).  So the odd head of a pair asks later, once
+    // the even head's fill has landed in L2.
+    const bool w_late = PCT_COL_W_LATE && (m & 1);
+    if (!w_late) load_weights();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // boxes in LDS before the barrier
     stamp(0);
     __syncthreads();                                                          // (A) boxes visible; pool free
@@ -800,6 +834,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
         if (ll == 0) stamp(8);                                                // first phase's LDS-DMA issued
         if constexpr (ll == 0) {
           if (have_n) decode(item_n, b_n, m_n, qv_n);                          // while the LDS-DMA pieces are in flight
+          if (w_late) load_weights();
         }
         if (ll == 0) stamp(3);
         __syncthreads();                                                      // windows staged (vmcnt(0) + barrier)
@@ -829,6 +864,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
     };
     if (!starts_phase[L - 1]) {                                               // (the finest level is gathered from global)
       if (have_n) decode(item_n, b_n, m_n, qv_n);
+      if (w_late) load_weights();
       stamp(3);
       stamp(4);
     }
@@ -860,6 +896,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       const unsigned oo[4] = {dpp_u<0x00>(own_o), dpp_u<0x55>(own_o), dpp_u<0xAA>(own_o), dpp_u<0xFF>(own_o)};
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4)
+        if (!PCT_COL_KO_NOSTORE || w4[s4][0] == 1.2345e30f)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(col_u32x4, w4[s4]), rs,
                                                (int)(oo[s4] + ((unsigned)(((qi - s4) + (int)rho) & 3) << 4)), 0,
                                                (STREAM_NT || PCT_COL_STORE_NT) ? 2 : 0);
@@ -907,7 +944,8 @@ int launch_msda_forward_col(const void *value, const int64_t *shapes, const int6
   const int wg_per_cu = one_wg ? 1 : ((BLOCKV == 256 && pool_kb <= 52) ? 3 : 2);
   const int pool_px = pool_kb * 1024 / 64;
   const size_t lds = (size_t)pool_px * 64 + ((size_t)(BLOCKV / 64) * L * 2 + 4) * sizeof(unsigned);   // pool, boxes, queue words
-  const dim3 grid(256 * wg_per_cu), block(BLOCKV);
+  static const int grid_env = [] { const char *e = getenv("PCT_COL_GRID_WG"); return e ? atoi(e) : 0; }();   // (diagnostic: workgroups per CU launched)
+  const dim3 grid(256 * ((grid_env >= 1 && grid_env <= wg_per_cu) ? grid_env : wg_per_cu)), block(BLOCKV);
   unsigned *queue = win_queue_slot(stream);                                    // nullptr: static item stride
   const float *v = static_cast<const float *>(value);
   const float *lc = static_cast<const float *>(loc), *at = static_cast<const float *>(attn);
