@@ -45,6 +45,9 @@ def sigmoid_focal_loss(inputs, targets, alpha: float = -1, gamma: float = 2, red
     return loss
 
 
+DISCRIMINATIVE_DENSE_BUDGET = 64 * 1024 * 1024      # pixels x labels above which discriminative_loss loops over instances
+
+
 def discriminative_loss(embedding, seg_gt, delta_v=0.5, delta_d=3, alpha=1, beta=1, gama=0.001):
     """Pull pixels to their instance centroid, push centroids apart (loss/loss.py:297-355)."""
     batch_size, embed_dim = embedding.shape[0], embedding.shape[1]
@@ -60,14 +63,25 @@ def discriminative_loss(embedding, seg_gt, delta_v=0.5, delta_d=3, alpha=1, beta
             zero = embedding.sum() * 0
             var_loss, dist_loss, reg_loss = var_loss + zero, dist_loss + zero, reg_loss + zero
             continue
-        # all instances at once: membership as a one-hot [pixels, labels] matrix, so centroids and per-instance means are
-        # two small matrix products (deterministic, unlike scatter-adds) instead of ~8 launches per instance
-        member = F.one_hot(inv, labels.numel()).to(emb_b.dtype)
-        count = member.sum(0)
-        mean = (emb_b @ member) / count                                          # [E, labels]
-        spread = (torch.norm(emb_b - mean[:, inv], dim=0) - delta_v) ** 2        # [pixels]
-        var_loss = var_loss + ((spread @ member) / count)[keep].sum() / num_id
-        centroids = mean[:, keep].t()                                            # [num_id, E]
+        if emb_b.shape[1] * labels.numel() > DISCRIMINATIVE_DENSE_BUDGET:
+            # a crowded, large sample (1024^2 pixels x 1000 instances would need ~4 GB for the membership matrix): the
+            # reference's per-instance loop, O(pixels) memory per instance
+            cents = []
+            for idx in labels[keep]:
+                emb_i = emb_b[:, gt_b == idx]
+                mean_i = emb_i.mean(dim=1)
+                cents.append(mean_i)
+                var_loss = var_loss + torch.mean((torch.norm(emb_i - mean_i.reshape(embed_dim, 1), dim=0) - delta_v) ** 2) / num_id
+            centroids = torch.stack(cents)
+        else:
+            # all instances at once: membership as a one-hot [pixels, labels] matrix, so centroids and per-instance means
+            # are two small matrix products (deterministic, unlike scatter-adds) instead of ~8 launches per instance
+            member = F.one_hot(inv, labels.numel()).to(emb_b.dtype)
+            count = member.sum(0)
+            mean = (emb_b @ member) / count                                      # [E, labels]
+            spread = (torch.norm(emb_b - mean[:, inv], dim=0) - delta_v) ** 2    # [pixels]
+            var_loss = var_loss + ((spread @ member) / count)[keep].sum() / num_id
+            centroids = mean[:, keep].t()                                        # [num_id, E]
         if num_id > 1:
             d = torch.norm(centroids.reshape(-1, 1, embed_dim) - centroids.reshape(1, -1, embed_dim), dim=2)
             d = d + torch.eye(num_id, dtype=d.dtype, device=d.device) * delta_d

@@ -42,6 +42,12 @@ absent: both are ordinary errors here and stay pinned by literal restatements in
 From connectomics/model/loss: dice_loss :23-42, sigmoid_ce_loss :50-67, calculate_uncertainty :101-115
 (maskformer_criterion.py) and batch_dice_loss :15-30, batch_sigmoid_ce_loss :38-62 (matcher.py).
 
+Round 3 -- the criterion's re-id / reference-point losses and the pixel-embedding loss: `SetCriterion.loss_reid_query`
+:318-350, `loss_reid_mask` :352-377, `loss_refpoints` :379-396 and `_get_src_permutation_idx` (loss/maskformer_criterion.py;
+methods taken from the class body and run with a bare namespace as `self` -- they touch nothing but torch) and
+`discriminative_loss` (loss/loss.py:297-355), fed the items the reference's own select_pos_neg_query / select_pos_neg_mask
+build; values AND input gradients are stored (loss_criterion.npz).
+
 This script reads the reference file as text, takes exactly those definitions out of its AST, executes them unmodified
 in a namespace holding torch / nn / F / math (no stand-ins for the missing libraries are written), feeds them seeded
 inputs and stores inputs + outputs as .npz fixtures next to this file.  Nothing of the reference's source is copied
@@ -195,6 +201,32 @@ def load_reference_losses(ref_root):
         exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
         out.update({k: ns[k] for k in names})
     return types.SimpleNamespace(**out)
+
+
+def load_reference_criterion(ref_root):
+    """The torch-only loss bodies of SetCriterion (methods, `self` is a bare namespace) and discriminative_loss."""
+    path = os.path.join(ref_root, "connectomics/model/loss/maskformer_criterion.py")
+    names = {"loss_reid_query", "loss_reid_mask", "loss_refpoints", "_get_src_permutation_idx"}
+    tree = ast.parse(open(path).read(), filename=path)
+    picked = []
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == "SetCriterion":
+            picked += [n for n in node.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(picked) == len(names)
+    ns = {"torch": torch, "F": F, "nn": nn}
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    path2 = os.path.join(ref_root, "connectomics/model/loss/loss.py")
+    tree2 = ast.parse(open(path2).read(), filename=path2)
+    picked2 = [n for n in tree2.body if isinstance(n, ast.FunctionDef) and n.name == "discriminative_loss"]
+    assert len(picked2) == 1
+    ns2 = {"torch": torch, "F": F, "nn": nn}
+    exec(compile(ast.Module(body=picked2, type_ignores=[]), path2, "exec"), ns2)
+    bag = types.SimpleNamespace()
+    bag._get_src_permutation_idx = types.MethodType(ns["_get_src_permutation_idx"], bag)
+    for k in ("loss_reid_query", "loss_reid_mask", "loss_refpoints"):
+        setattr(bag, k, types.MethodType(ns[k], bag))
+    bag.discriminative_loss = ns2["discriminative_loss"]
+    return bag
 
 
 def save(name, **arrays):
@@ -449,6 +481,77 @@ def main():
     # ---- dice_for (pairwise soft dice of the query masks, used by the query-contrast selection) ---------------------
     m = torch.randn(6, 9, 7, generator=g) * 3
     save("dec_dice_for", masks=m, dice=ref.dice_for(m))
+
+    # ---- round 3: criterion losses on the reference's own query-contrast items (own random stream: every fixture above
+    # is reproduced bit for bit) ------------------------------------------------------------------------------------------
+    import random
+    crit = load_reference_criterion(args.ref)
+    g3 = torch.Generator().manual_seed(20261004)
+    # 12 queries: a cluster of one positive still takes ALL its negatives into the auxiliary term (10 >= 12 - 2), so the
+    # loss does not depend on the iteration order of the reference's Python sets
+    Qc, Nc, C = 12, 3, 8
+    query = torch.randn(Qc, Nc, C, generator=g3).requires_grad_(True)
+    masks = (torch.randn(Nc, Qc, 6, 5, generator=g3) * 2).requires_grad_(True)
+    qn = query.detach().permute(1, 0, 2)
+    emb_dist = F.cosine_similarity(qn.unsqueeze(2), qn.unsqueeze(1), dim=-1)           # what dec.py:618-620 hands over
+    # (every image has a matched query: the reference's argmax over an empty positive list raises)
+    pos_indices = [(torch.tensor([1, 5, 9]), torch.tensor([0, 1, 2])), (torch.tensor([0, 11]), torch.tensor([1, 0])),
+                   (torch.tensor([4]), torch.tensor([0]))]
+    random.seed(5)
+    items_q = ref.select_pos_neg_query(query, emb_dist, pos_indices)
+    items_m = ref.select_pos_neg_mask(masks, emb_dist, pos_indices)
+    lq = crit.loss_reid_query({"pred_qd_query": items_q}, None, None, 1.0)
+    lm = crit.loss_reid_mask({"pred_qd_mask": items_m}, None, None, 1.0)
+    gq, = torch.autograd.grad(lq["loss_reid_query"] + 0.5 * lq["loss_reid_query_aux"], query)
+    gm, = torch.autograd.grad(lm["loss_reid_mask"], masks)
+    arrays = {"query": query.detach(), "masks": masks.detach(), "n_items": len(items_q),
+              "loss_reid_query": lq["loss_reid_query"].detach(), "loss_reid_query_aux": lq["loss_reid_query_aux"].detach(),
+              "loss_reid_mask": lm["loss_reid_mask"].detach(), "grad_query": gq, "grad_masks": gm}
+    for b, (src, tg) in enumerate(pos_indices):
+        arrays["pos_src_%d" % b], arrays["pos_tgt_%d" % b] = src, tg
+    # reference points
+    refp = torch.rand(Nc, Qc, 2, generator=g3).requires_grad_(True)
+    targets = [{"center_points": torch.rand(n, 1, 2, generator=g3)} for n in (3, 2, 1)]
+    lr = crit.loss_refpoints({"reference_points": refp}, targets, pos_indices, 2.5)
+    gr, = torch.autograd.grad(lr["loss_refpoints"], refp)
+    arrays.update({"reference_points": refp.detach(), "loss_refpoints": lr["loss_refpoints"].detach(), "grad_refpoints": gr,
+                   "num_masks": 2.5})
+    for b, t in enumerate(targets):
+        arrays["center_points_%d" % b] = t["center_points"]
+    # pixel-embedding loss: an image without instances, a label that does not occur, instances of one pixel
+    emb = torch.randn(3, 8, 12, 10, generator=g3).requires_grad_(True)
+    gt = torch.randint(0, 6, (3, 12, 10), generator=g3)
+    gt[1] = 0
+    gt[2][gt[2] == 3] = 4
+    gt[0, 0, 0] = 9
+    ld = crit.discriminative_loss(emb, gt)
+    ge, = torch.autograd.grad(ld, emb)
+    ld2 = crit.discriminative_loss(emb.detach(), gt, delta_v=0.3, delta_d=1.5, alpha=2.0, beta=0.5, gama=0.01)
+    arrays.update({"emb": emb.detach(), "seg_gt": gt, "loss_emb": ld.detach(), "grad_emb": ge, "loss_emb_params": ld2})
+    save("loss_criterion", **arrays)
+
+    # ---- round 3: the reference decoder / head under bf16 AUTOCAST (what bench.py times): the reference's own classes on
+    # the CPU autocast policy (torch.autocast("cpu", bfloat16): linear / conv / matmul / bmm in bf16), same inputs and
+    # parameters as dec_full_decoder / dec_head_l4.  The pixel decoder stays fp32 as the reference forces it on the device
+    # (msdeformattn.py:314 `@autocast(enabled=False)`): the head's two stages are therefore chained by hand, forward_features
+    # outside autocast, predictor inside (mask_former_head.py:141-154).  These are a yardstick, not a bit-level target: they
+    # say how far the REFERENCE moves from its own fp32 outputs when its GEMMs run in bf16.
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        out16 = decoder(xs, None, mfeat)
+    arrays = {"pred_masks": out16["pred_masks"].float(), "reference_points": out16["reference_points"].float(),
+              "n_aux": len(out16["aux_outputs"])}
+    for i, a in enumerate(out16["aux_outputs"]):
+        arrays["aux%d_pred_masks" % i] = a["pred_masks"].float()
+    save("dec_full_decoder_bf16", **arrays)
+    with torch.no_grad():
+        mf32, _, multi32 = pix.forward_features(feats)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            pred16 = head.predictor(multi32, None, mf32, None, head.attn_mask_threshold, None)
+    arrays = {"pred_masks": pred16["pred_masks"].float(), "reference_points": pred16["reference_points"].float(),
+              "n_aux": len(pred16["aux_outputs"])}
+    for i, a in enumerate(pred16["aux_outputs"]):
+        arrays["aux%d_pred_masks" % i] = a["pred_masks"].float()
+    save("dec_head_l4_bf16", **arrays)
 
 
 if __name__ == "__main__":

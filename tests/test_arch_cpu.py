@@ -285,3 +285,56 @@ def test_matcher_batched_costs_equal_the_per_image_loop():
     targets[1]["masks"] = (torch.rand(2, H + 2, W) < 0.3).float()
     assert m._batched_costs({"pred_masks": pred}, targets) is None
     assert len(m({"pred_masks": pred}, targets)) == 3
+
+
+# ---- instance_inference end to end (arch/maskformer.py:267-346 of the reference) ----------------------------------------
+def _instance_inference_literal(mask_pred, dataset):
+    """The reference's instance_inference restated line by line for both dataset branches (its CVPPP branch cannot run as
+    shipped: it imports imageio, writes prd_result.png and stops in pdb, :284-305), on the reference-pinned mask_post
+    (fixture arch_mask_post.npz) and the literal mask_nms above."""
+    mask_pred = mask_pred.sigmoid().float()
+    if dataset == "CVPPP":
+        pred_masks = (mask_pred > 0.69).float()
+        areas = torch.tensor([pred_masks[n].sum() for n in range(pred_masks.shape[0])])
+        pred_masks = pred_masks[areas > 40]
+        pred_masks = mfm.mask_post(pred_masks, thres1=0.5, thres2=0.6, bd_flag=True)
+        areas = torch.tensor([pred_masks[n].sum() for n in range(pred_masks.shape[0])])
+        pred_masks = _mask_nms_literal(pred_masks, (areas / areas.max()).to(pred_masks), 0.72)
+    else:
+        pred_masks = (mask_pred > 0.05).float()
+        areas = torch.tensor([pred_masks[n].sum() for n in range(pred_masks.shape[0])])
+        pred_masks = pred_masks[areas > 40]
+        pred_masks = mfm.mask_post(pred_masks, thres1=0.15, thres2=0.25)
+    areas = torch.tensor([pred_masks[n].sum() for n in range(pred_masks.shape[0])])
+    pred_masks = pred_masks[torch.argsort(areas).tolist()]
+    mask_scores = torch.cat([torch.zeros((1, pred_masks.shape[-2], pred_masks.shape[-1])).to(pred_masks), pred_masks])
+    return torch.argmax(mask_scores, axis=0).to(torch.int16)[None, :]
+
+
+def instance_logits(seed=0, H=96, W=88):
+    """Query mask logits with what the post-processing has to sort out: near-duplicate queries (merged), nested and
+    overlapping instances (NMS on CVPPP), soft edges around the thresholds, specks below the 40-pixel floor, empty
+    queries.  Every instance has its own area, so no argsort tie decides a label."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    specs = [(20, 20, 9.0), (20.5, 20.2, 9.3), (60, 30, 12.0), (60, 34, 6.5), (30, 60, 7.5), (75, 70, 10.5), (76, 71, 10.0),
+             (45, 45, 5.0), (10, 75, 3.0), (88, 10, 2.0), (50, 80, 8.2)]
+    logits = torch.full((len(specs) + 3, H, W), -9.0)
+    for i, (cy, cx, r) in enumerate(specs):
+        d = torch.sqrt((yy - cy) ** 2 + (xx - cx) ** 2)
+        logits[i] = (r - d) * 1.7 + 0.05 * torch.randn(H, W, generator=g)      # soft edge: sigmoid crosses 0.05 .. 0.69 over ~3 px
+    logits[-1] = -3.0 + 0.3 * torch.randn(H, W, generator=g)                     # a faint query: above 0.05 only in places
+    return logits
+
+
+@pytest.mark.parametrize("dataset", ["CVPPP", "BBBC"])
+def test_instance_inference_equals_the_literal_restatement(dataset):
+    net = mfm.MaskFormer(backbone=torch.nn.Identity(), sem_seg_head=torch.nn.Identity(),
+                         criterion=torch.nn.Identity(), num_queries=4, dataset_name=dataset)
+    logits = instance_logits()
+    out, bd = net.instance_inference(logits)
+    want = _instance_inference_literal(logits, dataset)
+    assert bd is None and out.dtype == torch.int16 and out.shape == want.shape
+    assert torch.equal(out, want)
+    assert len(out.unique()) >= 6                      # several instances survive, several queries were merged / dropped
+    assert len(out.unique()) - 1 < logits.shape[0] - 3

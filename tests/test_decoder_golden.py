@@ -341,3 +341,57 @@ def test_maskformer_head_on_the_hip_kernels_matches_the_reference_methods(golden
     with torch.no_grad():
         pred, mf = head({k: _t(g["feat_" + k]).cuda() for k in _PIX_CH})
     _check_head(g, pred, mf, 5e-4)
+
+
+# ---------------------------------------------------------------- the bf16 autocast path that bench.py times -----------------
+def _bf16_outputs_vs_reference(g32, g16, out, what):
+    """All-element bound of a bf16-autocast run against the REFERENCE's fp32 outputs, with the reference's own bf16-autocast
+    run (same classes, CPU autocast policy; *_bf16.npz) as the yardstick: every prediction head within
+    max(1.5 x the reference's own bf16 deviation, 1e-2 x scale), never beyond the absolute cap; the sign of the mask logits
+    (what attention masks and instances are cut from) agrees at least as often as the reference's bf16 run does, minus 1 %."""
+    scale = max(1.0, float(np.abs(g32["pred_masks"]).max()))
+    names = ["pred_masks"] + ["aux%d_pred_masks" % i for i in range(int(g32["n_aux"]))]
+    got = [out["pred_masks"]] + [a["pred_masks"] for a in out["aux_outputs"]]
+    worst = 0.0
+    for name, t in zip(names, got):
+        a = t.float().cpu().numpy()
+        ref32, ref16 = g32[name], g16[name]
+        own = float(np.abs(ref16 - ref32).max()) / scale              # the reference's own bf16 deviation
+        err = float(np.abs(a - ref32).max()) / scale
+        worst = max(worst, err)
+        assert err <= max(1.5 * own, 1e-2), "%s %s: max |err| %.4f x scale, reference bf16 itself %.4f" % (what, name, err, own)
+        agree = float(np.mean((a > 0) == (ref32 > 0)))
+        own_agree = float(np.mean((ref16 > 0) == (ref32 > 0)))
+        assert agree >= own_agree - 0.01, "%s %s: sign agreement %.4f, reference bf16 itself %.4f" % (what, name, agree, own_agree)
+    rp = float(np.abs(out["reference_points"].float().cpu().numpy() - g32["reference_points"]).max())
+    rp_own = float(np.abs(g16["reference_points"] - g32["reference_points"]).max())
+    assert rp <= max(1.5 * rp_own, 5e-3), "%s reference points: %.4f (reference bf16 itself %.4f)" % (what, rp, rp_own)
+    return worst
+
+
+@pytest.mark.gpu
+def test_whole_decoder_under_bf16_autocast_stays_within_the_references_own_bf16_deviation(golden):
+    """The route bench.py takes (torch.autocast('cuda', bfloat16) around the decoder: MFMA masked attention, MFMA dynamic
+    mask head, cached bf16 linears) against dec_full_decoder.npz (reference fp32) and dec_full_decoder_bf16.npz."""
+    g32, g16 = golden("dec_full_decoder"), golden("dec_full_decoder_bf16")
+    d = _full_decoder("cuda")
+    xs = [_t(g32["x%d" % i]).cuda() for i in range(3)]
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = d(xs, None, _t(g32["mask_features"]).cuda())
+    assert out["pred_masks"].dtype == torch.bfloat16
+    worst = _bf16_outputs_vs_reference(g32, g16, out, "decoder")
+    assert worst <= 0.05                                             # absolute cap, fraction of the largest logit
+
+
+@pytest.mark.gpu
+def test_head_under_bf16_autocast_stays_within_the_references_own_bf16_deviation(golden):
+    """MaskFormerHead as bench.py runs it: fp32 pixel decoder on the HIP kernels (msdeformattn.py:314 forces fp32), bf16
+    autocast transformer decoder, against dec_head_l4.npz (reference fp32) and dec_head_l4_bf16.npz."""
+    g32, g16 = golden("dec_head_l4"), golden("dec_head_l4_bf16")
+    head = _head("cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        pred, mf = head({k: _t(g32["feat_" + k]).cuda() for k in _PIX_CH})
+    assert mf.dtype == torch.float32 and pred["pred_masks"].dtype == torch.bfloat16
+    np.testing.assert_allclose(mf.cpu().numpy(), g32["mask_features"], rtol=0, atol=5e-4)      # the fp32 stage is not touched
+    worst = _bf16_outputs_vs_reference(g32, g16, pred, "head")
+    assert worst <= 0.2

@@ -100,6 +100,7 @@ def test_maskformer_train_step_and_eval_on_gpu():
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         out, _ = model(vol)
     assert out.shape == (2, H, W) and out.dtype == torch.int16
+    assert int(out.min()) >= 0 and int(out.max()) <= 12               # ids: background + at most one per query
 
 
 @pytest.mark.parametrize("name,depth,H,W,Q,levels,N", [
@@ -231,3 +232,26 @@ def test_two_eager_forwards_are_bitwise_equal_module_by_module():
         for x, y in zip(a[name], b[name]):
             d = float((x.float() - y.float()).abs().max())
             assert d <= 2.0 ** -6 * max(1.0, float(x.float().abs().max())), (name, d)
+
+
+@pytest.mark.parametrize("dataset", ["CVPPP", "BBBC"])
+def test_instance_inference_on_the_device_equals_the_cpu_path_and_the_literal_restatement(dataset):
+    """arch/maskformer.py:267-346 of the reference (instance_inference: threshold, 40-pixel floor, mask_post merge, NMS on
+    CVPPP, smallest-on-top label map): on device tensors (dice / intersections as GEMMs on the GPU, the greedy loops on one
+    device->host copy) the label map equals the package's CPU path and the line-by-line restatement of the reference on the
+    same logits -- both thresholds sets (CVPPP 0.69 / 0.5 / 0.6 / NMS 0.72, BBBC 0.05 / 0.15 / 0.25)."""
+    from pctrans_amd.arch import maskformer as mfm
+    from test_arch_cpu import _instance_inference_literal, instance_logits
+    net = mfm.MaskFormer(backbone=torch.nn.Identity(), sem_seg_head=torch.nn.Identity(),
+                         criterion=torch.nn.Identity(), num_queries=4, dataset_name=dataset)
+    logits = instance_logits()
+    want = _instance_inference_literal(logits, dataset)
+    cpu, _ = net.instance_inference(logits)
+    dev, bd = net.instance_inference(logits.cuda())
+    assert bd is None and dev.is_cuda and dev.dtype == torch.int16 and dev.shape == want.shape
+    assert torch.equal(cpu, want)
+    assert torch.equal(dev.cpu(), want)
+    assert len(want.unique()) >= 6
+    # bf16 logits (what the autocast decoder hands over): the same map as the CPU path on the same rounded logits
+    lb = logits.to(torch.bfloat16)
+    assert torch.equal(net.instance_inference(lb.cuda())[0].cpu(), net.instance_inference(lb)[0])
