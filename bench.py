@@ -353,7 +353,11 @@ def main():
     launches = MSDA.kernel_timing(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else device)
+    per_rank = [elapsed]
     if world > 1:
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                       # each rank's own wall time: a straggler shows in the JSON
+        per_rank = [float(x.item()) for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     assert torch.isfinite(pred["pred_masks"].float()).all(), "non-finite output"
@@ -381,6 +385,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step_per_rank": {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps,
+                                     "ranks": [1e3 * x / args.steps for x in per_rank]},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
