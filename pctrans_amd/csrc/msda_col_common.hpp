@@ -12,6 +12,11 @@ typedef float col_f32x4 __attribute__((ext_vector_type(4)));
 // first pixel x of column c (of C) on a level W pixels wide: the pixels whose centre (x + 0.5) / W lies in
 // [c / C, (c + 1) / C); every pixel belongs to exactly one column, col_lo(C) == W
 __device__ __forceinline__ int col_lo(const int c, const int W, const int C) { return (2 * c * W + C - 1) / (2 * C); }
+// the widest column: col_lo(c) = floor(c * s + d) with s = W / C and d = (C - 1) / (2 C) < 1/2, so consecutive columns
+// differ by floor(s) or floor(s) + 1, and as the C widths add up to W the larger one occurs whenever s is not an integer:
+// max_c (col_lo(c + 1) - col_lo(c)) = ceil(W / C).  (The kernels used to walk all columns of all levels with two integer
+// divisions each, in every workgroup, several times over: tens of microseconds before the first item of a launch.)
+__device__ __forceinline__ int col_max_cell(const int W, const int C) { return (W + C - 1) / C; }
 
 // a wave-uniform float, pinned to a scalar register: gfx950 has no scalar float unit, so a uniform float expression is
 // evaluated on the vector unit and -- hoisted out of the item loop -- would otherwise occupy a vector register for the

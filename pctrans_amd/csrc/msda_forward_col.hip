@@ -191,8 +191,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
 #pragma unroll
       for (int l = 0; l < L; ++l) {
         int mx = 0, my = 0;
-        for (int c = 0; c < CX; ++c) mx = max(mx, col_lo(c + 1, Ws[l], CX) - col_lo(c, Ws[l], CX));
-        for (int c = 0; c < CY; ++c) my = max(my, col_lo(c + 1, Hs[l], CY) - col_lo(c, Hs[l], CY));
+        mx = col_max_cell(Ws[l], CX);
+        my = col_max_cell(Hs[l], CY);
         maxq += mx * my;
       }
       if (maxq <= BLOCK) break;
@@ -217,8 +217,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
     for (int ll = 0; ll < L; ++ll) {
       const int l = L - 1 - ll;
       int mx = 0, my = 0;
-      for (int c = 0; c < CX; ++c) mx = max(mx, col_lo(c + 1, Ws[l], CX) - col_lo(c, Ws[l], CX));
-      for (int c = 0; c < CY; ++c) my = max(my, col_lo(c + 1, Hs[l], CY) - col_lo(c, Hs[l], CY));
+      mx = col_max_cell(Ws[l], CX);
+      my = col_max_cell(Hs[l], CY);
       const int cnt = mx * my;                                                 // (<= BLOCK <= 1024: x, y fit 10 bits)
       if (!placed && r < cnt) {
         const int ly = r / max(mx, 1), lx = r - ly * max(mx, 1);

@@ -23,6 +23,14 @@
 
 namespace pct {
 
+// Gather order of the levels (step -> level): finest, coarsest, then the rest (as in msda_forward_col.hip: the coarsest
+// level is the one that most often still fits beside the finest in the pool, which saves a phase).
+template <int L>
+__host__ __device__ constexpr int col16_level_of_step(const int ll)
+{
+  return ll == 0 ? L - 1 : (ll == 1 ? 0 : L - ll);
+}
+
 template <typename T, int L, int P, bool FUSED, int BLOCK>
 __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
     const typename Traits<T>::store_t *__restrict__ value, const int64_t *__restrict__ shapes,
@@ -81,8 +89,8 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
 #pragma unroll
       for (int l = 0; l < L; ++l) {
         int mx = 0, my = 0;
-        for (int c = 0; c < CX; ++c) mx = max(mx, col_lo(c + 1, Ws[l], CX) - col_lo(c, Ws[l], CX));
-        for (int c = 0; c < CY; ++c) my = max(my, col_lo(c + 1, Hs[l], CY) - col_lo(c, Hs[l], CY));
+        mx = col_max_cell(Ws[l], CX);
+        my = col_max_cell(Hs[l], CY);
         maxq += mx * my;
       }
       if (maxq <= QPW) break;
@@ -91,13 +99,55 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
       else break;
     }
   }
-  const int ncol = CX * CY;
+  // ---- this lane's SLOT in a column and the cell tables in LDS (as msda_forward_col.hip: a (query, head) pair's place --
+  // level, x, y inside the level's largest cell -- is fixed for the launch, the per-item decode is two table look-ups and
+  // a multiply-add instead of a walk over the levels with four scalar divisions each) ---------------------------------
+  int lane_c0 = 0;
+  unsigned lane_slot = 0x000FFFFFu;                                            // x | y << 10 | level << 20; x = y = 1023: no slot
+  {
+    int r = tid / HALVES;
+    bool placed = false;
+#pragma unroll
+    for (int ll = 0; ll < L; ++ll) {
+      const int l = L - 1 - ll;
+      const int mx = col_max_cell(Ws[l], CX), my = col_max_cell(Hs[l], CY);
+      const int cnt = mx * my;
+      if (!placed && r < cnt) {
+        const int ly = r / max(mx, 1), lx = r - ly * max(mx, 1);
+        lane_slot = (unsigned)lx | ((unsigned)ly << 10) | ((unsigned)l << 20);
+        lane_c0 = St[l] + ly * Ws[l] + lx;
+        placed = true;
+      }
+      r -= placed ? 0 : cnt;
+    }
+  }
+  const int tab_px = ((L * (CX + CY) + L) * 4 + PXB - 1) / PXB;
+  const int pool_eff = pool_px - tab_px;
+  unsigned *tab = reinterpret_cast<unsigned *>(pool + (size_t)max(pool_eff, 0) * PXB);
+  const bool use_tab = pool_eff * 2 >= pool_px;            // else: FLAT columns (absurdly elongated maps), see the decode
+  if (use_tab) {
+    for (int t = tid; t < L * CX; t += BLOCK) {
+      const int l = t / CX, c = t - l * CX;
+      const int a = col_lo(c, Ws[l], CX);
+      tab[t] = (unsigned)a | ((unsigned)(col_lo(c + 1, Ws[l], CX) - a) << 16);
+    }
+    for (int t = tid; t < L * CY; t += BLOCK) {
+      const int l = t / CY, c = t - l * CY;
+      const int a = col_lo(c, Hs[l], CY);
+      tab[L * CX + t] = (unsigned)a | ((unsigned)(col_lo(c + 1, Hs[l], CY) - a) << 16);
+    }
+    if (tid < L) tab[L * (CX + CY) + tid] = (unsigned)Ws[tid];
+    __syncthreads();
+  }
+  const int pool_use = use_tab ? pool_eff : pool_px;                           // pixels the windows may take
+  int ncol = CX * CY;
+  if (!use_tab) {
+    ncol = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) ncol += (Hs[l] * Ws[l] + QPW - 1) / QPW;
+  }
   const int items = N * ncol * M;
   const UDiv dv_ncolM = make_udiv(ncol * M), dv_2ncol = make_udiv(2 * ncol), dv_CX = make_udiv(CX);
-  const UDiv dv_2CX = make_udiv(2 * CX), dv_2CY = make_udiv(2 * CY);
-  auto col_lo_f = [&](const int c, const int W, const int C, const UDiv dv_2C) {   // == col_lo(c, W, C), scalar unit
-    return udiv_s(2 * c * W + C - 1, dv_2C);
-  };
 
   // pixels 0 and 1 of the pool are zeros: gated-out samples read them
   if (tid < 4) reinterpret_cast<col_f32x4 *>(pool)[tid] = col_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -131,25 +181,34 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
       m_ = M - 1;
     }
     const int cy = udiv_s(col, dv_CX), cx = col - cy * CX;
-    int q = 0, r = tid / HALVES, q_first = 0;
-    bool found = false, have_first = false;
+    int q;
+    bool valid;
+    if (use_tab) {
+      const unsigned lx = lane_slot & 0x3FFu, ly = (lane_slot >> 10) & 0x3FFu, lv = lane_slot >> 20;
+      const unsigned char *tb = reinterpret_cast<const unsigned char *>(tab);
+      const unsigned xt = *reinterpret_cast<const unsigned *>(tb + (__umul24(lv, (unsigned)(CX * 4)) + (unsigned)(cx * 4)));
+      const unsigned yt = *reinterpret_cast<const unsigned *>(tb + (__umul24(lv, (unsigned)(CY * 4)) + (unsigned)((L * CX + cy) * 4)));
+      const unsigned lw = *reinterpret_cast<const unsigned *>(tb + (lv * 4u + (unsigned)(L * (CX + CY) * 4)));
+      valid = lx < (xt >> 16) && ly < (yt >> 16);
+      q = lane_c0 + (int)__umul24(yt & 0xFFFFu, lw) + (int)(xt & 0xFFFFu);
+    } else {
+      int c = col;
+      q = 0;
+      valid = false;
 #pragma unroll
-    for (int ll = 0; ll < L; ++ll) {
-      const int l = L - 1 - ll;
-      const int xa = col_lo_f(cx, Ws[l], CX, dv_2CX), nx = col_lo_f(cx + 1, Ws[l], CX, dv_2CX) - xa;
-      const int ya = col_lo_f(cy, Hs[l], CY, dv_2CY), ny = col_lo_f(cy + 1, Hs[l], CY, dv_2CY) - ya;
-      const int cnt = nx * ny;
-      if (!have_first && cnt > 0) { have_first = true; q_first = St[l] + ya * Ws[l] + xa; }
-      const bool in = !found && r < cnt;
-      if (in) {
-        const int ly = (int)(((float)r + 0.5f) * uni(1.0f / (float)max(nx, 1)));
-        const int lx = r - ly * nx;
-        q = St[l] + (ya + ly) * Ws[l] + xa + lx;
-        found = true;
+      for (int l = 0; l < L; ++l) {
+        const int cnt = Hs[l] * Ws[l], nch = (cnt + QPW - 1) / QPW;
+        if (c >= 0 && c < nch) {
+          q = St[l] + c * QPW + tid / HALVES;
+          valid = c * QPW + tid / HALVES < cnt;
+        }
+        c = c >= nch ? c - nch : -1;
       }
-      r -= found ? 0 : cnt;
     }
-    qv_ = found ? q : ~q_first;
+    // idle lanes shadow a query of the column (the wave's first busy lane's; none: query 0 -- correct, merely wide boxes)
+    const unsigned long long vm = __ballot(valid);
+    const int q_sh = vm ? __builtin_amdgcn_readlane(q, (int)__builtin_ctzll(vm)) : 0;
+    qv_ = valid ? q : ~q_sh;
   };
   // this lane's 4 points of level l of its record: 32 contiguous bytes (per-image base uniform, 32-bit offsets)
   auto issue_loc_level = [&](auto lc, const int b_, const int m_, const int qv_, col_f32x4 (&raw)[L][2]) {
@@ -174,7 +233,7 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
   }
 
   while (have) {
-    asm volatile("" : "+v"(tid));                 // (opaque per iteration: see msda_forward_col.hip)
+    asm volatile("" : "+v"(tid), "+v"(lane_slot), "+v"(lane_c0));     // (opaque per iteration: see msda_forward_col.hip)
     const int hh = tid % HALVES;
     const bool valid = qv >= 0;
     const int q = valid ? qv : ~qv;
@@ -285,14 +344,14 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
       bool fresh = true;
 #pragma unroll
       for (int ll = 0; ll < L; ++ll) {
-        const int l = L - 1 - ll;
+        const int l = col16_level_of_step<L>(ll);
         starts_phase[l] = false;
-        if (wsize[l] > pool_px - 2) {
+        if (wsize[l] > pool_use - 2) {
           phase_of[l] = -1;
           wbase[l] = 0;
           continue;
         }
-        if (used + wsize[l] > pool_px - 2) {
+        if (used + wsize[l] > pool_use - 2) {
           ++ph;
           used = 0;
           fresh = true;
@@ -517,7 +576,7 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
     if (have_n && !starts_phase[L - 1]) decode(item_n, b_n, m_n, qv_n);
     auto level_step = [&](auto llc) {
       constexpr int ll = decltype(llc)::value;
-      constexpr int l = L - 1 - ll;
+      constexpr int l = col16_level_of_step<L>(ll);
       if (starts_phase[l]) {
         if (ll > 0) __syncthreads();
         stage_phase(phase_of[l]);
