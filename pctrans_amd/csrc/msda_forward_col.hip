@@ -251,6 +251,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
     __syncthreads();
   }
   const int pool_use = use_tab ? pool_eff : pool_px;                           // pixels the windows may take
+  bool big_map = false;                                                        // a level too large for the 16-bit box corners
+#pragma unroll
+  for (int l = 0; l < L; ++l) big_map = big_map || Ws[l] > 65531 || Hs[l] > 65531;
   int ncol = CX * CY;
   if (!use_tab) {
     ncol = 0;
@@ -562,7 +565,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       for (int ll = 0; ll < L; ++ll) {
         const int l = col_level_of_step<L>(ll);
         starts_phase[l] = false;
-        if (wsize[l] > pool_use) {                                             // never fits: gathered from global memory
+        // (never fits -- or a map too large for the 16-bit box corners --: gathered from global memory, which does not look at the box)
+        if (wsize[l] > pool_use || big_map) {
           phase_of[l] = -1;
           wbase[l] = 0;
           continue;

@@ -140,6 +140,9 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
     __syncthreads();
   }
   const int pool_use = use_tab ? pool_eff : pool_px;                           // pixels the windows may take
+  bool big_map = false;                                                        // a level too large for the 16-bit box corners
+#pragma unroll
+  for (int l = 0; l < L; ++l) big_map = big_map || Ws[l] > 65531 || Hs[l] > 65531;
   int ncol = CX * CY;
   if (!use_tab) {
     ncol = 0;
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
       for (int ll = 0; ll < L; ++ll) {
         const int l = col16_level_of_step<L>(ll);
         starts_phase[l] = false;
-        if (wsize[l] > pool_use - 2) {
+        if (wsize[l] > pool_use - 2 || big_map) {     // (or too large for the 16-bit box corners)
           phase_of[l] = -1;
           wbase[l] = 0;
           continue;
