@@ -55,6 +55,9 @@ namespace pct {
 #ifndef PCT_COL_ITEM_ORDER
 #define PCT_COL_ITEM_ORDER 0
 #endif
+#ifndef PCT_COL_EARLY
+#define PCT_COL_EARLY 1       /* the second phase's windows are staged into the finest level's region as soon as that level is gathered */
+#endif
 #ifndef PCT_COL_KO_NOSTAGE
 #define PCT_COL_KO_NOSTAGE 0  /* knock-out (WRONG RESULTS, timing only): no window staging (LDS-DMA) at all */
 #endif
@@ -584,6 +587,24 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       }
     }
 
+    // EARLY second phase.  With model-like offsets the four windows of a column need two phases ({finest, coarsest} and the
+    // two middle levels).  The finest level is gathered first and sits at the bottom of the pool, the second phase's windows
+    // are planned from the bottom too: when they fit inside the finest window's region, they are staged right behind the
+    // finest level's gather (one barrier: every wave is done with that region) and FLY while the coarsest level is gathered
+    // from its own region above -- instead of the workgroup sitting through that flight between two barriers later.
+    bool early_ok = false;
+    if constexpr (PCT_COL_EARLY && L >= 3) {
+      int used1 = 0;
+      bool has1 = false;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        used1 += phase_of[l] == 1 ? wsize[l] : 0;
+        has1 = has1 || phase_of[l] == 1;
+      }
+      early_ok = has1 && phase_of[L - 1] == 0 && phase_of[col_level_of_step<L>(1)] == 0 && wbase[L - 1] == 0 &&
+                 used1 <= wsize[L - 1];
+    }
+
     int woff[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) woff[l] = wbase[l] - wy0[l] * wwid[l] - wx0[l];
@@ -833,16 +854,20 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       constexpr int ll = decltype(llc)::value;
       constexpr int l = col_level_of_step<L>(ll);
       if (starts_phase[l]) {
-        if (ll > 0) __syncthreads();                                          // every wave is done with the pool
-        stage_phase(phase_of[l]);
-        if (ll == 0) stamp(8);                                                // first phase's LDS-DMA issued
-        if constexpr (ll == 0) {
-          if (have_n) decode(item_n, b_n, m_n, qv_n);                          // while the LDS-DMA pieces are in flight
-          if (w_late) load_weights();
+        if (ll > 0 && early_ok && phase_of[l] == 1) {
+          __syncthreads();                                                    // staged early (below): landed (vmcnt(0)) + visible
+        } else {
+          if (ll > 0) __syncthreads();                                        // every wave is done with the pool
+          stage_phase(phase_of[l]);
+          if (ll == 0) stamp(8);                                              // first phase's LDS-DMA issued
+          if constexpr (ll == 0) {
+            if (have_n) decode(item_n, b_n, m_n, qv_n);                        // while the LDS-DMA pieces are in flight
+            if (w_late) load_weights();
+          }
+          if (ll == 0) stamp(3);
+          __syncthreads();                                                    // windows staged (vmcnt(0) + barrier)
+          if (ll == 0) stamp(4);
         }
-        if (ll == 0) stamp(3);
-        __syncthreads();                                                      // windows staged (vmcnt(0) + barrier)
-        if (ll == 0) stamp(4);
       }
       if constexpr (ll == 0) {
         // (thread 0) park the counter value fetched at the top of the item: the weights below need the memory counter at
@@ -859,6 +884,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       else gather_level_global(std::integral_constant<int, l>{});             // box larger than the pool: global memory
       // (marking the global-memory path unlikely makes hipcc outline it behind a real call: 544 bytes of scratch per lane, 10x slower)
       if (ll == 0) stamp(10);                                                 // first level gathered
+      if constexpr (ll == 0 && PCT_COL_EARLY && L >= 3) {
+        if (early_ok) {
+          __syncthreads();                                                    // every wave is done with the finest window
+          stage_phase(1);
+        }
+      }
       // one group of the next item's location record per level: its registers are the ones this level's points freed
       // the next item's location record (32 registers: the ones this level's points and the weights freed)
       if constexpr (ll == (PCT_COL_LOC_AT < L ? PCT_COL_LOC_AT : L - 1)) {
