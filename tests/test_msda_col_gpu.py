@@ -85,18 +85,30 @@ COL_CASES = [
                     model_like=True)),
     ("col_M1_wide_strip", dict(seed=114, N=3, M=1, Lq=n_px([(2, 90), (4, 180), (8, 360)]),
                                shapes=[(2, 90), (4, 180), (8, 360)], model_like=True)),
+    # one-row maps 60 000 pixels long: 3 750 columns along x -- the cell tables would take most of the pool, so the launch
+    # runs on FLAT columns (256 consecutive queries of one level)
+    ("col_flat_columns_long_strip", dict(seed=115, N=1, M=2, Lq=n_px([(1, 15000), (1, 30000), (1, 60000)]),
+                                         shapes=[(1, 15000), (1, 30000), (1, 60000)], model_like=True, px_sigma=1.5, atol=2e-3)),
+    # a level wider than the 16-bit box corners can express (65 531): every level through the global-memory path
+    ("col_wider_than_the_box_corners", dict(seed=116, N=1, M=2, Lq=n_px([(1, 17500), (1, 35000), (1, 70000)]),
+                                            shapes=[(1, 17500), (1, 35000), (1, 70000)], model_like=True, px_sigma=1.5, atol=2e-3)),
 ]
 
 
 @pytest.mark.parametrize("cid,kw", COL_CASES, ids=[c[0] for c in COL_CASES])
 def test_column_kernel_vs_oracle(MSDA, lib, cid, kw):
     kw = dict(dict(M=8, D=16, P=4), **kw)
+    # (atol override: on a map 60 000 pixels wide one ulp of a fp32 pixel coordinate is 2^-8 px, and `loc * W - 0.5` rounds
+    # once as an FMA -- here and under nvcc's default contraction in the reference -- but twice in the oracle's plain C)
+    atol = kw.pop("atol", 1e-4)
     c = make_case(dtype=np.float32, **kw)
     want = orc.forward(c["value"], c["shapes"], c["starts"], c["loc"], c["attn"])
     with force(lib, K_COL):
         got = run_fwd(MSDA, c)
         assert lib.pct_msda_last_kernel() == K_COL
-    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(got, want, rtol=0, atol=atol)
+    if atol > 1e-4:                                  # ... and almost every element still agrees to 1e-4
+        assert float(np.mean(np.abs(got - want) <= 1e-4)) > 0.9999
 
 
 def test_column_kernel_inf_in_a_window_does_not_leak(MSDA, lib):
@@ -239,7 +251,8 @@ def test_config5_16bit_P8_L5_default_route_vs_oracle(MSDA, lib, tdt, eps, N, sha
     got = MSDA.ms_deform_attn_forward(v16.cuda(), dev(c["shapes"]), dev(c["starts"]), dev(c["loc"]), dev(c["attn"]), 64)
     assert lib.pct_msda_last_kernel() == (K_COL if N * S * 8 * 2 >= 160000 else K_DPP) and got.dtype == tdt
     err = np.abs(got.float().cpu().numpy() - want)
-    assert np.all(err <= eps * np.abs(want) + 1e-5), float(err.max())
+    slack = 2e-3 if max(w for _, w in shapes) > 20000 else 1e-5          # (fp32 coordinate resolution on very wide maps, see above)
+    assert np.all(err <= eps * np.abs(want) + slack), float(err.max())
 
 
 def test_config5_fullsize_properties(MSDA, lib):
@@ -346,6 +359,7 @@ COL16_CASES = [
     ("c16_P4_L3_uniform", 4, P1, dict(N=2)),
     ("c16_P4_L5_model", 4, [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64)], dict(N=2, model_like=True, px_sigma=1.0)),
     ("c16_P8_M3_heads", 8, [(9, 12), (18, 24), (36, 48)], dict(N=2, M=3, model_like=True)),
+    ("c16_P4_flat_columns_long_strip", 4, [(1, 15000), (1, 30000), (1, 60000)], dict(N=1, M=2, model_like=True, px_sigma=1.5)),
 ]
 
 
@@ -360,4 +374,5 @@ def test_column_kernel_16bit_vs_oracle(MSDA, lib, cid, P, shapes, kw, tdt, eps):
         got = MSDA.ms_deform_attn_forward(v16.cuda(), dev(c["shapes"]), dev(c["starts"]), dev(c["loc"]), dev(c["attn"]), 64)
         assert lib.pct_msda_last_kernel() == K_COL and got.dtype == tdt
     err = np.abs(got.float().cpu().numpy() - want)
-    assert np.all(err <= eps * np.abs(want) + 1e-5), float(err.max())
+    slack = 2e-3 if max(w for _, w in shapes) > 20000 else 1e-5          # (fp32 coordinate resolution on very wide maps, see above)
+    assert np.all(err <= eps * np.abs(want) + slack), float(err.max())
