@@ -255,3 +255,63 @@ def test_instance_inference_on_the_device_equals_the_cpu_path_and_the_literal_re
     # bf16 logits (what the autocast decoder hands over): the same map as the CPU path on the same rounded logits
     lb = logits.to(torch.bfloat16)
     assert torch.equal(net.instance_inference(lb.cuda())[0].cpu(), net.instance_inference(lb)[0])
+
+
+def test_graphed_training_front_gives_the_eager_step(tmp_path):
+    """graph.graph_training_front: backbone + pixel decoder forward AND backward replayed from HIP graphs inside an otherwise
+    eager training step -- same losses and gradients as the eager step on the same inputs (up to the float-atomic noise of the
+    MSDeformAttn backward), parameters / state dict / eval path untouched, BatchNorm statistics not moved by the capture."""
+    import copy
+    import random
+    from pctrans_amd import graph
+    from pctrans_amd.arch import maskformer as mfm
+    from pctrans_amd.arch.resnet import ResNet
+    from pctrans_amd.config import get_cfg
+    from test_arch_cpu import _blob
+    torch.manual_seed(0)
+    cfg = get_cfg(num_queries=12, norm="BN", sem_norm="BN", enc_layers=2, dec_layers=3, train_num_points=512, dataset="BBBC")
+    eager = mfm.MaskFormer(**mfm.MaskFormer.from_config(cfg, ResNet(18, 3, norm="BN"))).cuda().train()
+    graphed = copy.deepcopy(eager)
+    H = W = 128
+    vol = torch.randn(2, 3, H, W, device="cuda")
+    targets = []
+    for b in range(2):
+        masks = torch.stack([_blob(H, W, 30, 30, 14), _blob(H, W, 90, 80, 20), _blob(H, W, 40, 100 - 9 * b, 10)]).cuda()
+        centers = torch.tensor([[30 / W, 30 / H], [80 / W, 90 / H], [(100 - 9 * b) / W, 40 / H]], device="cuda").view(3, 1, 2)
+        targets.append({"masks": masks, "labels": torch.ones(3, dtype=torch.long, device="cuda"),
+                        "fg_masks": (masks.sum(0) > 0).float(), "center_points": centers})
+    names = sorted(k for k, _ in eager.named_parameters())
+    stats = {n: b.clone() for n, b in graphed.named_buffers()}
+    graph.graph_training_front(graphed, vol)
+    assert sorted(k for k, _ in graphed.named_parameters()) == names             # nothing fell out of the module tree
+    assert sorted(graphed.state_dict()) == sorted(eager.state_dict())
+    for n, b in graphed.named_buffers():
+        assert torch.equal(b, stats[n]), n                                        # capture passes did not move the statistics
+
+    def step(model):
+        random.seed(3)
+        torch.manual_seed(3)
+        losses = model(vol, targets, True)
+        total = sum(v for v in losses.values() if torch.is_tensor(v))
+        model.zero_grad(set_to_none=True)
+        total.backward()
+        return float(total.detach()), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    le, ge = step(eager)
+    lg, gg = step(graphed)
+    assert abs(le - lg) <= 2e-4 * max(1.0, abs(le)), (le, lg)
+    assert ge.keys() == gg.keys()
+    for n in ge:
+        scale = max(1e-6, float(ge[n].abs().max()))
+        assert float((ge[n] - gg[n]).abs().max()) <= 5e-3 * scale + 1e-6, n
+    lg2, _ = step(graphed)                                                         # a second replay: same answer
+    assert abs(lg2 - lg) <= 2e-4 * max(1.0, abs(lg))
+    graphed.eval()
+    eager.eval()
+    with torch.no_grad():
+        a, _ = graphed(vol)
+        b, _ = eager(vol)
+    assert a.shape == b.shape                                                      # the eval path is the eager one
+    with pytest.raises(ValueError):
+        graphed.train()
+        graphed(vol[:, :, :96], targets, True)

@@ -53,6 +53,9 @@ def build(c):
         targets.append({"masks": masks, "labels": torch.ones(G, dtype=torch.long, device="cuda"),
                         "fg_masks": (masks.sum(0) > 0).float(), "center_points": centers})
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05)
+    if c.get("graph_front"):
+        from pctrans_amd.graph import graph_training_front
+        graph_training_front(model, vol)
 
     def step():
         losses = model(vol, targets, True)
@@ -66,7 +69,10 @@ def build(c):
 
 def main():
     out = {"device": torch.cuda.get_device_name(0), "note": __doc__.split("\n\n")[0], "configs": {}}
-    for name, c in CONFIGS.items():
+    configs = dict(CONFIGS)
+    if "--graph-front" in sys.argv:
+        configs.update({k + " + graphed backbone / pixel decoder": dict(v, graph_front=True) for k, v in CONFIGS.items()})
+    for name, c in configs.items():
         model, step = build(c)
         for _ in range(3):
             step()
