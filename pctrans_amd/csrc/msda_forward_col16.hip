@@ -595,6 +595,7 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
         }
         front_end();
       }
+      __builtin_amdgcn_s_setprio(ll == 0 ? 3 : 2);          // (the gather before the other workgroups' bookkeeping: msda_forward_col.hip)
       if (phase_of[l] >= 0) gather_level_lds(std::integral_constant<int, l>{});
       else gather_level_global(std::integral_constant<int, l>{});
       if (have_n) issue_loc_level(std::integral_constant<int, ll>{}, b_n, m_n, qv_n, raw);   // level ll of the next item
@@ -602,6 +603,7 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
     [&]<int... LLs>(std::integer_sequence<int, LLs...>) {
       (level_step(std::integral_constant<int, LLs>{}), ...);
     }(std::make_integer_sequence<int, L>{});
+    __builtin_amdgcn_s_setprio(0);
 
     // ---- store: slot 0 of lane h holds piece rho = h (P = 8) -- add the partner's slot 1 -- or both pieces (P = 4) ----
     if constexpr (HALVES == 2) {
