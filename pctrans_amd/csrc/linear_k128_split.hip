@@ -27,6 +27,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#ifndef PCT_LIN_PRIO
+#define PCT_LIN_PRIO 0
+#endif
+
 namespace pct {
 
 typedef float spl_f32x16 __attribute__((ext_vector_type(16)));
@@ -254,6 +258,9 @@ __global__ __launch_bounds__(SPL_BLOCK, 2) void linear_k128_split_kernel(
       spl_bf16x8 n1 = *reinterpret_cast<const spl_bf16x8 *>(ap);
       spl_bf16x8 n2 = *reinterpret_cast<const spl_bf16x8 *>(ap + SPL_PLANE);
       spl_bf16x8 n3 = *reinterpret_cast<const spl_bf16x8 *>(ap + 2 * SPL_PLANE);
+#if PCT_LIN_PRIO
+      __builtin_amdgcn_s_setprio(PCT_LIN_PRIO);                   // (the wave feeding the matrix pipe before its SIMD-mate's split / epilogue)
+#endif
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const spl_bf16x8 a1 = n1, a2 = n2, a3 = n3;
@@ -274,6 +281,9 @@ __global__ __launch_bounds__(SPL_BLOCK, 2) void linear_k128_split_kernel(
         acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a1, acc_lo, 0, 0, 0);
       }
     }
+#if PCT_LIN_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     stash(abuf[buf ^ 1], gn, g2);
 
     {

@@ -19,6 +19,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef PCT_LIN_PRIO
+#define PCT_LIN_PRIO 0
+#endif
+
 namespace pct {
 
 typedef float lls_f32x16 __attribute__((ext_vector_type(16)));
@@ -151,6 +155,9 @@ __global__ __launch_bounds__(LLS_BLOCK, 2) void linear_ln_split_kernel(
       const bool last = step + 1 == ksteps;
       fetch(last ? tile + gridDim.x : tile, last ? 0 : step + 1);
       __builtin_amdgcn_sched_barrier(0);
+#if PCT_LIN_PRIO
+      __builtin_amdgcn_s_setprio(PCT_LIN_PRIO);
+#endif
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         lls_bf16x8 a[2][3], w[2][3];
@@ -175,6 +182,9 @@ __global__ __launch_bounds__(LLS_BLOCK, 2) void linear_ln_split_kernel(
       }
     }
 
+#if PCT_LIN_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // ---- epilogue: acc[rb][cb][4q + i] = y[row 64 wr + 32 rb + r][column 64 wc + 32 cb + 8q + 4h + i] ----------------
     const auto rr = tile_rsrc(R, ldr, tile);
     const auto ry = tile_rsrc(Y, ldy, tile);

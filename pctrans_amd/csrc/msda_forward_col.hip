@@ -72,6 +72,9 @@ namespace pct {
 #define PCT_COL_PRIO_L0 3
 #define PCT_COL_PRIO_REST 2
 #endif
+#ifndef PCT_COL_PRIO_FRONT
+#define PCT_COL_PRIO_FRONT 0
+#endif
 #ifndef PCT_COL_KO_NOSTAGE
 #define PCT_COL_KO_NOSTAGE 0  /* knock-out (WRONG RESULTS, timing only): no window staging (LDS-DMA) at all */
 #endif
@@ -884,6 +887,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
           __syncthreads();                                                    // windows staged (vmcnt(0) + barrier)
           if (ll == 0) stamp(4);
           if (ll == 0 && PCT_COL_PRIO == 4) __builtin_amdgcn_s_setprio(0);
+          if (ll == 0 && PCT_COL_PRIO == 8 && PCT_COL_PRIO_FRONT) __builtin_amdgcn_s_setprio(PCT_COL_PRIO_L0);   // weights / soft-max too
         }
       }
       if constexpr (ll == 0) {

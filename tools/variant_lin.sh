@@ -1,0 +1,21 @@
+#!/bin/bash
+# As tools/variant.sh, for the split-bf16 GEMM kernels: tools/variant_lin.sh <name> [-DPCT_LIN_PRIO=2 ...] -> ab_libs/lib<name>.so
+set -e
+cd "$(dirname "$0")/.."
+name=$1; shift
+mkdir -p ab_libs/_obj_$name
+make -C pctrans_amd/csrc -j8 >/dev/null
+FL="-O3 -std=c++20 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -fvisibility=hidden -Wall -Wno-unused-result"
+objs=""
+for f in pctrans_amd/csrc/_obj/*.o; do
+  b=$(basename $f .o)
+  if [ "$b" = linear_k128_split ] || [ "$b" = linear_ln_split ]; then
+    /opt/rocm/bin/hipcc $FL "$@" -c pctrans_amd/csrc/$b.hip -o ab_libs/_obj_$name/$b.o &
+    objs="$objs ab_libs/_obj_$name/$b.o"
+  else
+    objs="$objs $f"
+  fi
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_libs/lib$name.so $objs
+echo "built ab_libs/lib$name.so ($*)"
