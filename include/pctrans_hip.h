@@ -179,6 +179,13 @@ PCT_API int pct_linear_k128_f32(const float *x, long long ldx, const float *x_ad
  *   atomics; concurrent callers see each other's values. */
 PCT_API void pct_msda_set_kernel_choice(int choice);
 PCT_API int pct_msda_last_kernel(void);
+/* The same for the backward (pct_ms_deform_attn_backward_f32): choice 0 = auto (fp32, Lq == S, D = 16, 4 points and enough
+ *   columns to fill the chip: pyramid-column kernel, msda_backward_col.hip; else the windowed kernel; else generic),
+ *   1 = windowed, 2 = generic, 3 = pyramid-column (also below the size threshold), anything else = follow
+ *   PCT_MSDA_BWD_KERNEL (auto | win | generic | col) again.  pct_msda_last_bwd_kernel: 1 = windowed, 2 = generic,
+ *   3 = pyramid-column, 0 = none yet. */
+PCT_API void pct_msda_set_bwd_kernel_choice(int choice);
+PCT_API int pct_msda_last_bwd_kernel(void);
 
 /* pct_linear_k128_multi_f32: nseg (1..4) Linear layers over the SAME rows in one launch, y[s] = (x [+ x_add]) . w[s]^T
  *   + bias[s]: MSDeformAttn's value_proj(src), sampling_offsets(src + pos) and attention_weights(src + pos)

@@ -27,6 +27,8 @@ SYMBOLS = {
                              ctypes.c_longlong, _vp], _i),
     "pct_msda_set_kernel_choice": ([_i], None),
     "pct_msda_last_kernel": ([], _i),
+    "pct_msda_set_bwd_kernel_choice": ([_i], None),
+    "pct_msda_last_bwd_kernel": ([], _i),
     "pct_linear_k128_multi_f32": ([_vp, ctypes.c_longlong, _vp, ctypes.c_longlong, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp,
                                    _vp, _vp, ctypes.c_longlong, _vp], _i),
     "pct_linear_k128_add_layernorm_f32": ([_vp, ctypes.c_longlong, _vp, _vp, _vp, ctypes.c_longlong, _vp, _vp,

@@ -19,6 +19,8 @@ int launch_linear_k128(const float *x, long long ldx, const float *x2, long long
                        const float *beta, float eps, hipStream_t stream);
 void set_msda_kernel_choice(int v);
 int msda_last_kernel();
+void set_msda_bwd_kernel_choice(int c);
+int msda_bwd_last_kernel();
 int launch_linear_k128_split_multi(const float *x, long long ldx, const float *x2, long long ldx2, long long x2_period,
                                    int nseg, const float *const *w, const float *const *bias, const int *n,
                                    const int *use_add, float *const *y, const long long *ldy, long long rows,
@@ -291,6 +293,10 @@ int pct_linear_k128_f32(const float *x, long long ldx, const float *x_add, long 
 void pct_msda_set_kernel_choice(int choice) { pct::set_msda_kernel_choice(choice); }
 
 int pct_msda_last_kernel(void) { return pct::msda_last_kernel(); }
+
+void pct_msda_set_bwd_kernel_choice(int choice) { pct::set_msda_bwd_kernel_choice(choice); }
+
+int pct_msda_last_bwd_kernel(void) { return pct::msda_bwd_last_kernel(); }
 
 int pct_linear_k128_multi_f32(const float *x, long long ldx, const float *x_add, long long ld_add, long long add_period,
                               int nseg, const float *const *w, const float *const *bias, const int *n, const int *use_add,

@@ -169,6 +169,13 @@ __global__ __launch_bounds__(BWD_BLOCK) void msda_backward_kernel(
 int launch_msda_backward_win(const float *value, const int64_t *shapes, const int64_t *starts, const float *loc,
                              const float *attn, const float *grad_out, int N, int S, int M, int D, int L, int Lq,
                              int P, float *grad_value, float *grad_loc, float *grad_attn, hipStream_t stream);
+// msda_backward_col.hip: the pyramid-column kernel and the backward's kernel choice (0 = auto, 1 = windowed, 2 = generic,
+// 3 = pyramid-column) / record of the kernel launched last (1 = windowed, 2 = generic, 3 = pyramid-column)
+int launch_msda_backward_col(const float *value, const int64_t *shapes, const int64_t *starts, const float *loc,
+                             const float *attn, const float *grad_out, int N, int S, int M, int D, int L, int Lq,
+                             int P, float *grad_value, float *grad_loc, float *grad_attn, bool forced, hipStream_t stream);
+int msda_bwd_kernel_choice();
+void note_msda_bwd_kernel(int k);
 
 template <typename A>
 int launch_msda_backward(const void *value, const int64_t *shapes, const int64_t *starts, const void *loc,
@@ -193,19 +200,31 @@ int launch_msda_backward(const void *value, const int64_t *shapes, const int64_t
   }
   if (total_lanes == 0) return 0;
   if constexpr (sizeof(A) == 4) {
-    // PCT_MSDA_BWD_KERNEL = auto (windowed when the queries are the pyramid's own pixels) | win | generic
-    static const int mode = [] {
-      const char *e = getenv("PCT_MSDA_BWD_KERNEL");
-      return !e ? 0 : (!strcmp(e, "win") ? 1 : (!strcmp(e, "generic") ? 2 : 0));
-    }();
+    // PCT_MSDA_BWD_KERNEL = auto (pyramid-column when the queries are the pyramid's own pixels and the problem fills the
+    // chip, else windowed, else generic) | col | win | generic; pct_msda_set_bwd_kernel_choice overrides the environment
+    const int mode = msda_bwd_kernel_choice();
+    if (shfl && (mode == 0 || mode == 3) && Lq == S) {
+      const int rc = launch_msda_backward_col(
+          static_cast<const float *>(value), shapes, starts, static_cast<const float *>(loc),
+          static_cast<const float *>(attn), static_cast<const float *>(grad_out), N, S, M, D, L, Lq, P,
+          static_cast<float *>(grad_value), static_cast<float *>(grad_loc), static_cast<float *>(grad_attn), mode == 3, stream);
+      if (rc != -100) {
+        note_msda_bwd_kernel(3);
+        return rc;
+      }
+    }
     if (shfl && mode != 2 && (mode == 1 || Lq == S)) {
       const int rc = launch_msda_backward_win(
           static_cast<const float *>(value), shapes, starts, static_cast<const float *>(loc),
           static_cast<const float *>(attn), static_cast<const float *>(grad_out), N, S, M, D, L, Lq, P,
           static_cast<float *>(grad_value), static_cast<float *>(grad_loc), static_cast<float *>(grad_attn), stream);
-      if (rc != -100) return rc;
+      if (rc != -100) {
+        note_msda_bwd_kernel(1);
+        return rc;
+      }
     }
   }
+  note_msda_bwd_kernel(2);
   const long long nblk = (total_lanes + BWD_BLOCK - 1) / BWD_BLOCK;
   if (nblk > 0x7fffffffLL) return -4;
   const int rec_stride = sizeof(A) == 4 ? padded_record_stride(LP * 3) : LP * 3 + 1;

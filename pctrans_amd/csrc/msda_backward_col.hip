@@ -1,0 +1,778 @@
+// MSDeformAttn backward, "pyramid-column" kernel for MI355X (gfx950, wave64): fp32, D = 16, P = 4, Lq == S.
+//
+// Same semantics as msda_backward.hip (reference: ops/src/cuda/ms_deform_im2col_cuda.cuh:92-164 per sample, channel sums
+// as in cuh:306-408; host side ops/src/cuda/ms_deform_attn_cuda.cu:88-158).
+//
+// Why a second windowed backward: msda_backward_win.hip (round 1) works on 8 x 16 query tiles of ONE level.  A tile of a
+// coarse level looking at a fine level has a box the pool cannot hold -- those levels are retried slot by slot or fall to
+// direct global atomics -- and knock-out builds showed that neither the LDS adds (31 %) nor the flush (7 %) but this
+// skeleton is what the kernel spends its time in (2.6 of 3.8 ms at P2, batch 32).  Here the work item is the forward's
+// (msda_forward_col.hip): (image, pyramid COLUMN, head) -- the queries of all levels over one cell of a CX x CY grid, one
+// window per level serving the whole column -- and one lane = one (query, head) with all 16 channels:
+//   * pass 1 ("dots"): the value windows are staged by LDS-DMA with the forward's zero apron (the gate of cuh:290-296 is
+//     folded into the coordinates), every sample reads its four head-pixels (rotated 16-byte pieces, as the forward) and
+//     forms the four dot products <grad_out, v_corner> IN THE LANE -- no cross-lane butterflies -- from which
+//     grad_attn_weight and grad_sampling_loc follow (cuh:115-163 rearranged: sum_c w_c d_c, W a (hh (d2 - d1) + lh (d4 - d3)), ...);
+//   * pass 2 ("scatter"): the SAME pool then holds the grad_value windows, channel-pair planar, as 64-bit integer
+//     accumulators: a packed FMA with the 1.5 * 2^23 magic constant leaves round(w_c a g scale) of two channels in the
+//     low mantissa bits of a register pair, and ONE ds_add_u64 adds both raw bit patterns (measured: 6.4 cycles per wave
+//     instruction against 2 x 4.3 for ds_add_u32, and no per-value integer subtraction).  A 17th plane counts the
+//     contributions n per texel; the flush recovers both 32-bit sums exactly from (T, n): low = T_lo - n K, carry =
+//     (n K + low) >> 32, high = T_hi - carry - n K (K = 0x4B400000).  Integer sums: deterministic, order-independent;
+//     scale = one power of two per item from max|grad_out| max|attn|, 2^-20 of that bound per contribution, 1024
+//     contributions cannot overflow; non-finite bounds send the item down the direct float path;
+//   * one coalesced flush per window: two global float atomics per (texel, channel pair) with n > 0, lanes on
+//     consecutive dwords;
+//   * the two passes share one pool (values, then accumulators), so a workgroup holds 1080 window pixels in 74 KB: the four
+//     windows of a column with model-like offsets (~1 300 px) take two phases, the reference's init-like ones a single one;
+//   * levels whose box exceeds the pool use the direct path (global gathers + float atomics, reference summation order).
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <utility>
+
+#include "msda_col_common.hpp"
+
+namespace pct {
+
+#ifndef PCT_BCOL_KO
+#define PCT_BCOL_KO 0         /* knock-outs (WRONG RESULTS, timing only): 1 = no scatter adds, 2 = no dots reads, 4 = no flush atomics */
+#endif
+
+constexpr int BCOL_BLOCK = 256;
+constexpr int BCOL_GPX = 1080;                                  // pixels per pool (= 24 mod 32: the flush's plane reads spread over the banks)
+constexpr int BCOL_CNT_BYTES = BCOL_GPX * 4;                    // contribution counts, one dword per pixel
+constexpr int BCOL_PLANE_BYTES = BCOL_GPX * 8;                  // one channel-pair plane of 64-bit accumulators
+constexpr int BCOL_POOL_BYTES = (BCOL_CNT_BYTES + 8 * BCOL_PLANE_BYTES + 63) & ~63;   // >= BCOL_GPX * 64 (the value windows)
+constexpr int BCOL_TAB_BYTES = 4096;                            // cell tables
+static_assert(BCOL_POOL_BYTES >= BCOL_GPX * 64, "value windows must fit the pool");
+static_assert(BCOL_CNT_BYTES + 7 * BCOL_PLANE_BYTES + 8 < 65536, "ds immediate offsets");
+
+template <int L>
+__host__ __device__ constexpr int bcol_level_of_step(const int ll)   // finest, coarsest, then the middle levels (as the forward)
+{
+  return ll == 0 ? L - 1 : (ll == 1 ? 0 : L - ll);
+}
+
+template <int L>
+__global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
+    const float *__restrict__ grad_out, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn, const int N,
+    const int S, const int M, float *__restrict__ grad_value, float *__restrict__ grad_loc,
+    float *__restrict__ grad_attn, unsigned *__restrict__ queue)
+{
+  constexpr int P = 4, D = 16, PXB = 64, BLOCK = BCOL_BLOCK, NW = BLOCK / 64;
+  static_assert(L >= 1 && L <= 5, "unsupported geometry");
+  typedef unsigned col_u32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+  typedef __attribute__((address_space(3))) unsigned lds_u32;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char *pool = smem_raw;                                              // value windows (64 B per head-pixel) / accumulators
+  unsigned *tab = reinterpret_cast<unsigned *>(smem_raw + BCOL_POOL_BYTES);    // cell tables
+  unsigned *bb = tab + BCOL_TAB_BYTES / 4;                                     // [L][NW][2] per-wave boxes {min lo, ~max hi}
+  unsigned *mx = bb + NW * 5 * 2;                                              // [NW][2] max |grad_out| bits, max |attn| bits
+  unsigned *next_idx = mx + NW * 2;                                            // the workgroup's next item
+
+  int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int MD = M * D;
+
+  // ---- level geometry (uniform) -------------------------------------------------------------------------------------
+  int Hs[L], Ws[L], St[L];
+  col_f32x2 fWH[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    Hs[l] = (int)shapes[2 * l];
+    Ws[l] = (int)shapes[2 * l + 1];
+    St[l] = (int)starts[l];
+    fWH[l] = uni_pair((float)Ws[l], (float)Hs[l]);
+  }
+
+  // ---- column grid and this lane's slot: exactly the forward's (msda_forward_col.hip) ---------------------------------
+  int CX, CY;
+  {
+    int Hf = Hs[0], Wf = Ws[0];
+#pragma unroll
+    for (int l = 1; l < L; ++l)
+      if (Hs[l] * Ws[l] > Hf * Wf) { Hf = Hs[l]; Wf = Ws[l]; }
+    const float area = (float)BLOCK * (float)(Hf * Wf) / (float)S;
+    const int side = (int)sqrtf(area);
+    const int nxt = min(Wf, max(8, (side + 4) & ~7));
+    CX = (Wf + nxt - 1) / nxt;
+    const int nx0 = (Wf + CX - 1) / CX;
+    const int nyt = max(1, (int)(area / (float)nx0));
+    CY = min(Hf, (Hf + nyt - 1) / nyt);
+    for (int guard = 0; guard < 4096; ++guard) {
+      int maxq = 0;
+#pragma unroll
+      for (int l = 0; l < L; ++l) maxq += col_max_cell(Ws[l], CX) * col_max_cell(Hs[l], CY);
+      if (maxq <= BLOCK) break;
+      if (CY < Hf) ++CY;
+      else if (CX < Wf) ++CX;
+      else break;
+    }
+  }
+  int lane_c0 = 0;
+  unsigned lane_slot = 0x000FFFFFu;                                            // x | y << 10 | level << 20; x = y = 1023: no slot
+  {
+    int r = tid;
+    bool placed = false;
+#pragma unroll
+    for (int ll = 0; ll < L; ++ll) {
+      const int l = L - 1 - ll;
+      const int mxc = col_max_cell(Ws[l], CX), myc = col_max_cell(Hs[l], CY);
+      const int cnt = mxc * myc;
+      if (!placed && r < cnt) {
+        const int ly = r / max(mxc, 1), lx = r - ly * max(mxc, 1);
+        lane_slot = (unsigned)lx | ((unsigned)ly << 10) | ((unsigned)l << 20);
+        lane_c0 = St[l] + ly * Ws[l] + lx;
+        placed = true;
+      }
+      r -= placed ? 0 : cnt;
+    }
+  }
+  const bool use_tab = (L * (CX + CY) + L) * 4 <= BCOL_TAB_BYTES;
+  if (use_tab) {
+    for (int t = tid; t < L * CX; t += BLOCK) {
+      const int l = t / CX, c = t - l * CX;
+      const int a = col_lo(c, Ws[l], CX);
+      tab[t] = (unsigned)a | ((unsigned)(col_lo(c + 1, Ws[l], CX) - a) << 16);
+    }
+    for (int t = tid; t < L * CY; t += BLOCK) {
+      const int l = t / CY, c = t - l * CY;
+      const int a = col_lo(c, Hs[l], CY);
+      tab[L * CX + t] = (unsigned)a | ((unsigned)(col_lo(c + 1, Hs[l], CY) - a) << 16);
+    }
+    if (tid < L) tab[L * (CX + CY) + tid] = (unsigned)Ws[tid];
+    __syncthreads();
+  }
+  constexpr int pool_use = BCOL_GPX;
+  bool big_map = false;                                                        // a level too large for the 16-bit box corners
+#pragma unroll
+  for (int l = 0; l < L; ++l) big_map = big_map || Ws[l] > 65531 || Hs[l] > 65531;
+  int ncol = CX * CY;
+  if (!use_tab) {
+    ncol = 0;
+#pragma unroll
+    for (int l = 0; l < L; ++l) ncol += (Hs[l] * Ws[l] + BLOCK - 1) / BLOCK;
+  }
+  const int items = N * ncol * M;
+  const UDiv dv_ncolM = make_udiv(ncol * M), dv_2ncol = make_udiv(2 * ncol), dv_CX = make_udiv(CX);
+
+  int qi = lane & 3;
+  const bool qi0 = qi & 1, qi1 = qi & 2;
+  const unsigned rho = (unsigned)(lane >> 3) & 3u;                             // rotation of a head-pixel's 16-byte pieces
+  unsigned rot[4], prot[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    rot[j] = ((j + rho) & 3u) << 4;                                            // byte offset of the piece register j reads
+    prot[j] = (unsigned)BCOL_CNT_BYTES + ((j + rho) & 3u) * (unsigned)(2 * BCOL_PLANE_BYTES);   // ... and its first accumulator plane
+  }
+
+  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int chunk = (items + 7) / 8;
+  const int item_end = min((xcd + 1) * chunk, items);
+  const unsigned n_x = (unsigned)max(item_end - xcd * chunk, 0);
+
+  constexpr int NPL = L * 2, NGL = (NPL + 3) / 4;                              // locations: 16-byte pieces, 64-byte groups
+  constexpr int NGW = (L + 3) / 4;                                             // weights: one 16-byte piece per level
+
+  // item -> (image, head) [uniform] and this lane's query (qv = q, or ~q of the query an idle lane shadows); item order
+  // inside an image: head pair, column, head in the pair (the forward's)
+  auto decode = [&](const int it, int &b_, int &m_, int &qv_) {
+    b_ = udiv_s(it, dv_ncolM);
+    const int r_img = it - b_ * (ncol * M);
+    int col;
+    if (r_img < 2 * ncol * (M >> 1)) {
+      const int pr = udiv_s(r_img, dv_2ncol);
+      const int rr = r_img - pr * 2 * ncol;
+      col = rr >> 1;
+      m_ = 2 * pr + (rr & 1);
+    } else {
+      col = r_img - 2 * ncol * (M >> 1);
+      m_ = M - 1;
+    }
+    const int cy = udiv_s(col, dv_CX), cx = col - cy * CX;
+    int q;
+    bool valid;
+    if (use_tab) {
+      const unsigned lx = lane_slot & 0x3FFu, ly = (lane_slot >> 10) & 0x3FFu, lv = lane_slot >> 20;
+      const unsigned char *tb = reinterpret_cast<const unsigned char *>(tab);
+      const unsigned xt = *reinterpret_cast<const unsigned *>(tb + (__umul24(lv, (unsigned)(CX * 4)) + (unsigned)(cx * 4)));
+      const unsigned yt = *reinterpret_cast<const unsigned *>(tb + (__umul24(lv, (unsigned)(CY * 4)) + (unsigned)((L * CX + cy) * 4)));
+      const unsigned lw = *reinterpret_cast<const unsigned *>(tb + (lv * 4u + (unsigned)(L * (CX + CY) * 4)));
+      valid = lx < (xt >> 16) && ly < (yt >> 16);
+      q = lane_c0 + (int)__umul24(yt & 0xFFFFu, lw) + (int)(xt & 0xFFFFu);
+    } else {
+      int c = col;
+      q = 0;
+      valid = false;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const int cnt = Hs[l] * Ws[l], nch = (cnt + BLOCK - 1) / BLOCK;
+        if (c >= 0 && c < nch) {
+          q = St[l] + c * BLOCK + tid;
+          valid = c * BLOCK + tid < cnt;
+        }
+        c = c >= nch ? c - nch : -1;
+      }
+    }
+    const unsigned long long vm = __ballot(valid);
+    const int q_sh = vm ? __builtin_amdgcn_readlane(q, (int)__builtin_ctzll(vm)) : 0;
+    qv_ = valid ? q : ~q_sh;
+  };
+  auto rec_index = [&](const int qv_, const int m_) {
+    return __umul24((unsigned)(qv_ ^ (qv_ >> 31)), (unsigned)M) + (unsigned)m_;
+  };
+  auto quad_offsets = [&](const unsigned own_bytes, unsigned (&off)[4]) {
+    off[0] = dpp_u<0x00>(own_bytes) + ((unsigned)((0 - qi) & 3) << 4);
+    off[1] = dpp_u<0x55>(own_bytes) + ((unsigned)((1 - qi) & 3) << 4);
+    off[2] = dpp_u<0xAA>(own_bytes) + ((unsigned)((2 - qi) & 3) << 4);
+    off[3] = dpp_u<0xFF>(own_bytes) + ((unsigned)((3 - qi) & 3) << 4);
+  };
+  constexpr int RSRC_FLAGS = 0x00020000;
+  auto issue_loc = [&](const int b_, const int m_, const int qv_, col_f32x4 (&raw)[NGL][4]) {
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(loc + (long long)b_ * S * M * (L * P * 2)), 0,
+                                                      (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 8)), RSRC_FLAGS);
+    unsigned off[4];
+    quad_offsets(rec_index(qv_, m_) * (unsigned)(L * P * 8), off);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int g = 0; g < NGL; ++g)
+        raw[g][s4] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off[s4] + g * 64), 0, 0));
+  };
+
+  int item = xcd * chunk + slot0;
+  bool have = item < item_end;
+  int b = 0, m = 0, qv = 0;
+  col_f32x4 raw[NGL][4];
+  if (have) {
+    decode(item, b, m, qv);
+    issue_loc(b, m, qv, raw);
+  }
+
+  while (have) {
+    asm volatile("" : "+v"(tid), "+v"(qi), "+v"(lane_slot), "+v"(lane_c0));
+    unsigned rfetch = 0u;
+    if (queue && tid == 0) rfetch = atomicAdd(queue + xcd, 1u);
+    const unsigned own = rec_index(qv, m);                                    // this lane's record: query * M + head
+    const bool idle = qv < 0;
+
+    // ---- the record: pixel coordinates (w_im, h_im) = loc * (W, H) - 0.5 (cuh:283-288) with the gate of cuh:290-296 folded
+    // in as in the forward: a coordinate that fails its test (NaN included) moves to -2, one past the map to W; the staged
+    // window carries a zero apron of two pixels, so such a sample reads zeros (all its gradients are exactly 0 for finite
+    // grad_out) and adds into apron accumulators that are never flushed.
+    col_f32x2 lxy[L][P];
+    {
+#pragma unroll
+      for (int g = 0; g < NGL; ++g) quad_transpose_in(raw[g], qi0, qi1);
+#pragma unroll
+      for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+          const col_f32x4 pc = raw[(l * 2 + k / 2) / 4][(l * 2 + k / 2) & 3];
+          const col_f32x2 v = {pc[(k & 1) * 2], pc[(k & 1) * 2 + 1]};
+          const col_f32x2 px = __builtin_elementwise_fma(v, fWH[l], col_f32x2{-0.5f, -0.5f});
+          lxy[l][k][0] = fminf(px[0] > -1.f ? px[0] : -2.f, fWH[l][0]);
+          lxy[l][k][1] = fminf(px[1] > -1.f ? px[1] : -2.f, fWH[l][1]);
+        }
+    }
+
+    // ---- pre-pass: per-level bounding box (the forward's) ---------------------------------------------------------------
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const float mnx = fminf(fminf(lxy[l][0][0], lxy[l][1][0]), fminf(lxy[l][2][0], lxy[l][3][0]));
+      const float mxx = fmaxf(fmaxf(lxy[l][0][0], lxy[l][1][0]), fmaxf(lxy[l][2][0], lxy[l][3][0]));
+      const float mny = fminf(fminf(lxy[l][0][1], lxy[l][1][1]), fminf(lxy[l][2][1], lxy[l][3][1]));
+      const float mxy = fmaxf(fmaxf(lxy[l][0][1], lxy[l][1][1]), fmaxf(lxy[l][2][1], lxy[l][3][1]));
+      const unsigned lo = (unsigned)(cvt_flr(mnx) + 2) | ((unsigned)(cvt_flr(mny) + 2) << 16);
+      const unsigned hi = (unsigned)(cvt_flr(mxx) + 3) | ((unsigned)(cvt_flr(mxy) + 3) << 16);
+      const unsigned red = wave_reduce_box(lo, hi);                 // lane 31: min lo, lane 63: ~max hi
+      if ((lane & 31) == 31) bb[(l * NW + wave) * 2 + (lane >> 5)] = red;
+    }
+    // ---- this item's weights and grad_output rows (quad-cooperative, looked at after the staging is issued) ----------------
+    col_f32x4 wraw[NGW][4], graw[4];
+    {
+      const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(attn + (long long)b * S * M * (L * P)), 0,
+                                                         (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 4)), RSRC_FLAGS);
+      const auto rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(grad_out + (long long)b * S * MD), 0,
+                                                         (int)((unsigned)S * (unsigned)MD * 4u), RSRC_FLAGS);
+      unsigned off[4], ofg[4];
+      quad_offsets(own * (unsigned)(L * P * 4), off);
+      quad_offsets(own * (unsigned)(D * 4), ofg);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+        for (int g = 0; g < NGW; ++g)
+          wraw[g][s4] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)(off[s4] + g * 64), 0, 0));
+        graw[s4] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, (int)ofg[s4], 0, 0));
+      }
+    }
+    if (tid == 0) {
+      unsigned fetched = (unsigned)(item - xcd * chunk + nslots);             // static stride when there is no queue
+      if (queue) {
+        if (rfetch + 1u >= n_x) atomicExch(queue + xcd, 0u);                   // that was the launch's last fetch
+        fetched = (unsigned)nslots + rfetch;
+      }
+      next_idx[0] = fetched;
+    }
+    __syncthreads();                                                          // (A) boxes visible; pool free (previous flush read)
+    int item_n, b_n = 0, m_n = 0, qv_n = 0;
+    {
+      const unsigned nxt = __builtin_amdgcn_readfirstlane(next_idx[0]);
+      item_n = nxt < n_x ? xcd * chunk + (int)nxt : item_end;
+    }
+    const bool have_n = item_n < item_end;
+
+    // ---- windows and phases (uniform; the forward's planning) ---------------------------------------------------------------
+    int wx0[L], wy0[L], wwid[L], whgt[L], wsize[L], wbase[L], phase_of[L], woff[L];
+    int nph = 0;
+    {
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        unsigned lo, hi;
+        block_box<NW>(bb + l * NW * 2, lo, hi);
+        const unsigned lx = lo & 0xFFFFu, ly = lo >> 16;
+        wx0[l] = (int)lx - 2;
+        wy0[l] = (int)ly - 2;
+        wwid[l] = (int)((hi & 0xFFFFu) - lx) + 1;
+        whgt[l] = (int)((hi >> 16) - ly) + 1;
+        wsize[l] = wwid[l] * whgt[l];
+      }
+      int ph = 0, used = 0;
+      bool any = false;
+#pragma unroll
+      for (int ll = 0; ll < L; ++ll) {
+        const int l = bcol_level_of_step<L>(ll);
+        if (wsize[l] > pool_use || big_map) {
+          phase_of[l] = -1;
+          wbase[l] = 0;
+          continue;
+        }
+        if (used + wsize[l] > pool_use) {
+          ++ph;
+          used = 0;
+        }
+        phase_of[l] = ph;
+        wbase[l] = used;
+        used += wsize[l];
+        any = true;
+      }
+      nph = any ? ph + 1 : 0;
+#pragma unroll
+      for (int l = 0; l < L; ++l) woff[l] = wbase[l] - wy0[l] * wwid[l] - wx0[l];
+    }
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value + (long long)b * S * MD), 0,
+                                                        (int)((unsigned)S * (unsigned)MD * 4u), RSRC_FLAGS);
+    float *gimg = grad_value + (long long)b * S * MD + m * D;                 // this image, this head
+
+    // stage the value windows of one phase by LDS-DMA (the forward's stage_phase)
+    auto stage_phase = [&](const int phx) {
+      constexpr int PPX = PXB / 16, CPX = 64 / PPX;
+      constexpr unsigned OOB = 0x80000000u;
+      const int ln = tid & 63;
+      const int dx = ln / PPX, cc = ln & (PPX - 1);
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const unsigned MDb = (unsigned)MD * 4u;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        if (phase_of[l] == phx && wsize[l] > 0) {
+          const unsigned lvl_off = (unsigned)St[l] * MDb + (unsigned)(m * D) * 4u;
+          const unsigned row_bytes = (unsigned)Ws[l] * MDb;
+          unsigned char *dst = pool + (size_t)wbase[l] * PXB;
+          for (int c0 = 0; c0 < wwid[l]; c0 += CPX) {
+            const int xw = c0 + dx, x = wx0[l] + xw;
+            const unsigned voff = (unsigned)x < (unsigned)Ws[l] ? (unsigned)x * MDb + (unsigned)(cc * 16) : OOB;
+            if (xw < wwid[l]) {
+              for (int r = wv; r < whgt[l]; r += NW) {
+                const int y = wy0[l] + r;
+                const bool in_y = (unsigned)y < (unsigned)Hs[l];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rsrc, (__attribute__((address_space(3))) void *)(dst + (size_t)(r * wwid[l] + c0) * PXB), 16,
+                    (int)(in_y ? voff : OOB), (int)(in_y ? lvl_off + (unsigned)y * row_bytes : 0u), 0, 0);
+              }
+            }
+          }
+        }
+      }
+    };
+
+    if (nph > 0) stage_phase(0);
+    if (have_n) decode(item_n, b_n, m_n, qv_n);                                // while the LDS-DMA pieces are in flight
+
+    // ---- weights, grad_output (rotated like the head-pixel pieces), the item's magnitude bounds -------------------------------
+    float wts[L][P];
+    col_f32x2 go2[4][2];                                                       // register j: channels of piece (j + rho) % 4
+    {
+#pragma unroll
+      for (int g = 0; g < NGW; ++g) quad_transpose_in(wraw[g], qi0, qi1);
+      quad_transpose_in(graw, qi0, qi1);
+      rot_regs(graw, rho & 1u, rho & 2u);
+      unsigned gmax = 0u, amax = 0u;                                           // |x| as bits: Inf / NaN compare largest
+#pragma unroll
+      for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+          wts[l][k] = idle ? 0.f : wraw[l / 4][l & 3][k];
+          amax = max(amax, __float_as_uint(wts[l][k]) & 0x7fffffffu);
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gv = idle ? 0.f : graw[j][e];
+          gmax = max(gmax, __float_as_uint(gv) & 0x7fffffffu);
+          go2[j][e >> 1][e & 1] = gv;
+        }
+      }
+      gmax = wave_reduce_umax(gmax);
+      amax = wave_reduce_umax(amax);
+      if (lane == 0) {
+        mx[wave * 2] = gmax;
+        mx[wave * 2 + 1] = amax;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                                          // (B1) phase 0 staged; bounds visible
+    bool fixed_ok;
+    float scale, inv_scale;
+    {
+      unsigned gb = 0u, ab = 0u;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        gb = max(gb, mx[w * 2]);
+        ab = max(ab, mx[w * 2 + 1]);
+      }
+      gb = __builtin_amdgcn_readfirstlane(gb);
+      ab = __builtin_amdgcn_readfirstlane(ab);
+      const float C = __builtin_bit_cast(float, gb) * __builtin_bit_cast(float, ab);
+      int e;
+      (void)frexpf(C, &e);                                                    // C < 2^e
+      fixed_ok = gb < 0x7f800000u && ab < 0x7f800000u && C < 1e30f;
+      // a window dword receives at most BLOCK * P = 1024 contributions w_corner * attn * grad_out, each below C < 2^e:
+      // rounded to multiples of 2^(e - 20), the int32 sums stay below 2^30
+      const int shift = max(min(20 - e, 100), -100);
+      scale = uni(ldexpf(1.f, shift));
+      inv_scale = uni(ldexpf(1.f, -shift));
+    }
+    if (have_n) issue_loc(b_n, m_n, qv_n, raw);                               // in flight until the next iteration
+
+    float ga[L][P];
+    col_f32x2 gl[L][P];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int k = 0; k < P; ++k) {
+        ga[l][k] = 0.f;
+        gl[l][k] = col_f32x2{0.f, 0.f};
+      }
+
+    // ---- pass 1 of a level from its LDS window: four dot products per sample ---------------------------------------------
+    auto dots_lds = [&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+        ([&] {
+          constexpr int k = Ks;
+          // (opaque: the compiler otherwise forms every sample's geometry at the top of the item and keeps it alive)
+          asm volatile("" : "+v"(lxy[l][k]));
+          const col_f32x2 pix = lxy[l][k];
+          const int x0 = cvt_flr(pix[0]), y0 = cvt_flr(pix[1]);
+          const float lw = __builtin_amdgcn_fractf(pix[0]), lh = __builtin_amdgcn_fractf(pix[1]);
+          const float hw = 1.f - lw, hh = 1.f - lh;
+          const unsigned a = (unsigned)(__mul24(y0, wwid[l]) + x0 + woff[l]) << 6;
+          const unsigned rowb = (unsigned)wwid[l] << 6;
+          float d[4];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            col_f32x4 va[4], vb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const unsigned char *pa = pool + (a + (r ? rowb : 0u) + rot[j]);
+              if (PCT_BCOL_KO & 2) {
+                va[j] = col_f32x4{(float)a, 1.f, 2.f, 3.f};
+                vb[j] = va[j];
+              } else {
+                va[j] = *reinterpret_cast<const col_f32x4 *>(pa);
+                vb[j] = *reinterpret_cast<const col_f32x4 *>(pa + PXB);
+              }
+            }
+            col_f32x2 sa = {0.f, 0.f}, sb = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                sa = __builtin_elementwise_fma(go2[j][e], col_f32x2{va[j][2 * e], va[j][2 * e + 1]}, sa);
+                sb = __builtin_elementwise_fma(go2[j][e], col_f32x2{vb[j][2 * e], vb[j][2 * e + 1]}, sb);
+              }
+            d[2 * r] = sa[0] + sa[1];
+            d[2 * r + 1] = sb[0] + sb[1];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // cuh:115-163 with the channel sums taken first: d_c = <grad_out, v_c>
+          ga[l][k] = hh * (hw * d[0] + lw * d[1]) + lh * (hw * d[2] + lw * d[3]);
+          const float aw = wts[l][k];
+          gl[l][k][0] = aw * fWH[l][0] * (hh * (d[1] - d[0]) + lh * (d[3] - d[2]));
+          gl[l][k][1] = aw * fWH[l][1] * (hw * (d[2] - d[0]) + lw * (d[3] - d[1]));
+        }(), ...);
+      }(std::make_integer_sequence<int, P>{});
+    };
+    // ---- pass 2: round(w_c * attn * grad_out * scale) of two channels per 64-bit add, one count per corner ---------------
+    auto scatter_lds = [&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      const col_f32x2 magic2 = {12582912.f, 12582912.f};                      // 1.5 * 2^23
+      [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+        ([&] {
+          constexpr int k = Ks;
+          asm volatile("" : "+v"(lxy[l][k]));
+          const col_f32x2 pix = lxy[l][k];
+          const int x0 = cvt_flr(pix[0]), y0 = cvt_flr(pix[1]);
+          const float lw = __builtin_amdgcn_fractf(pix[0]), lh = __builtin_amdgcn_fractf(pix[1]);
+          const float as = wts[l][k] * scale;
+          const col_f32x2 t = col_f32x2{1.f - lw, lw} * col_f32x2{as, as};
+          const col_f32x2 g12 = t * col_f32x2{1.f - lh, 1.f - lh}, g34 = t * col_f32x2{lh, lh};
+          const unsigned pidx = (unsigned)(__mul24(y0, wwid[l]) + x0 + woff[l]);
+          if (!(PCT_BCOL_KO & 1)) {
+            lds_u32 *cp = (lds_u32 *)(pool + pidx * 4u);
+            lds_u32 *cq = (lds_u32 *)(pool + (pidx + (unsigned)wwid[l]) * 4u);
+            __hip_atomic_fetch_add(cp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(cp + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(cq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(cq + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const unsigned pr = (pidx + (r ? (unsigned)wwid[l] : 0u)) * 8u;
+            const col_f32x2 wa = r ? col_f32x2{g34[0], g34[0]} : col_f32x2{g12[0], g12[0]};
+            const col_f32x2 wb = r ? col_f32x2{g34[1], g34[1]} : col_f32x2{g12[1], g12[1]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              unsigned char *pp = pool + (pr + prot[j]);
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const col_f32x2 xa = __builtin_elementwise_fma(wa, go2[j][e], magic2);
+                const col_f32x2 xb = __builtin_elementwise_fma(wb, go2[j][e], magic2);
+                if (!(PCT_BCOL_KO & 1)) {
+                  lds_u64 *q = (lds_u64 *)(pp + e * BCOL_PLANE_BYTES);
+                  __hip_atomic_fetch_add(q, __builtin_bit_cast(unsigned long long, xa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  __hip_atomic_fetch_add(q + 1, __builtin_bit_cast(unsigned long long, xb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                  asm volatile("" ::"v"(xa), "v"(xb));
+                }
+              }
+              // (without the fence the compiler forms the 64 packed products of a sample -- of several samples -- first
+              // and spills them on the way to the adds)
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }(), ...);
+      }(std::make_integer_sequence<int, P>{});
+    };
+    // ---- flush of one window: (T, n) -> the two 32-bit sums -> two float atomics per (texel, channel pair) with n > 0 -------
+    auto flush_window = [&](const int l) {
+      const float inv_w = 1.0f / (float)wwid[l];
+      const int n8 = wsize[l] * 8;
+      float *glev = gimg + (long long)St[l] * MD;
+      const int H = Hs[l], W = Ws[l];
+      for (int i = tid; i < n8; i += BLOCK) {
+        const int px = i >> 3, pair = i & 7;
+        const int r = (int)(((float)px + 0.5f) * inv_w);
+        const int y = wy0[l] + r, x = wx0[l] + px - r * wwid[l];
+        const bool inside = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        const unsigned n = *reinterpret_cast<const unsigned *>(pool + (size_t)(wbase[l] + px) * 4);
+        if (inside && n != 0u) {
+          const unsigned long long T = *reinterpret_cast<const unsigned long long *>(
+              pool + BCOL_CNT_BYTES + (size_t)pair * BCOL_PLANE_BYTES + (size_t)(wbase[l] + px) * 8);
+          constexpr unsigned K = 0x4B400000u;
+          const unsigned nK = n * K;
+          const int lo = (int)((unsigned)T - nK);
+          const unsigned long long U = (unsigned long long)n * K + (unsigned long long)(long long)lo;
+          const int hi = (int)((unsigned)(T >> 32) - (unsigned)(U >> 32) - nK);
+          float *dst = glev + (long long)(y * W + x) * MD + 2 * pair;
+          if (!(PCT_BCOL_KO & 4)) {
+            if (lo != 0) unsafeAtomicAdd(dst, (float)lo * inv_scale);
+            if (hi != 0) unsafeAtomicAdd(dst + 1, (float)hi * inv_scale);
+          }
+        }
+      }
+    };
+    // ---- a level on the direct path: global gathers, float atomics, the reference's summation order (cuh:104-163) ---------
+    auto level_global = [&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      const int H = Hs[l], W = Ws[l];
+      const float *vimg = value + (long long)b * S * MD + m * D;
+      [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+        ([&] {
+          constexpr int k = Ks;
+          const col_f32x2 pix = lxy[l][k];
+          const int x0 = cvt_flr(pix[0]), y0 = cvt_flr(pix[1]);                // inside [-2, W] x [-2, H]
+          const float lw = __builtin_amdgcn_fractf(pix[0]), lh = __builtin_amdgcn_fractf(pix[1]);
+          const float hw = 1.f - lw, hh = 1.f - lh;
+          const bool top = (unsigned)y0 < (unsigned)H, bot = (unsigned)(y0 + 1) < (unsigned)H;
+          const bool lft = (unsigned)x0 < (unsigned)W, rgt = (unsigned)(x0 + 1) < (unsigned)W;
+          const bool ok[4] = {top && lft, top && rgt, bot && lft, bot && rgt};
+          const long long e0 = (long long)(St[l] + y0 * W + x0) * MD;
+          const long long eo[4] = {e0, e0 + MD, e0 + (long long)W * MD, e0 + (long long)W * MD + MD};
+          const float wc[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+          const float aw = wts[l][k];
+          float s_a = 0.f, s_w = 0.f, s_h = 0.f;
+          const bool any = !idle && (ok[0] || ok[1] || ok[2] || ok[3]);
+          if (any) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ch0 = (int)(((unsigned)j + rho) & 3u) * 4;
+              col_f32x4 v[4];
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                v[c] = ok[c] ? *reinterpret_cast<const col_f32x4 *>(vimg + eo[c] + ch0) : col_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float g = go2[j][e >> 1][e & 1];
+                const float tgv = g * aw;                                      // top_grad_value (cuh:112)
+                float gh = -(hw * v[0][e]);
+                gh = fmaf(-lw, v[1][e], gh);
+                gh = fmaf(hw, v[2][e], gh);
+                gh = fmaf(lw, v[3][e], gh);
+                float gw = -(hh * v[0][e]);
+                gw = fmaf(hh, v[1][e], gw);
+                gw = fmaf(-lh, v[2][e], gw);
+                gw = fmaf(lh, v[3][e], gw);
+                float val = wc[0] * v[0][e];
+                val = fmaf(wc[1], v[1][e], val);
+                val = fmaf(wc[2], v[2][e], val);
+                val = fmaf(wc[3], v[3][e], val);
+                s_a = fmaf(g, val, s_a);
+                s_w = fmaf(gw, tgv, s_w);
+                s_h = fmaf(gh, tgv, s_h);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                  if (ok[c]) unsafeAtomicAdd(gimg + eo[c] + ch0 + e, wc[c] * tgv);
+              }
+            }
+          }
+          ga[l][k] = any ? s_a : 0.f;
+          gl[l][k][0] = any ? s_w * fWH[l][0] : 0.f;
+          gl[l][k][1] = any ? s_h * fWH[l][1] : 0.f;
+        }(), ...);
+      }(std::make_integer_sequence<int, P>{});
+    };
+
+#pragma unroll 1
+    for (int ph = 0; ph < nph; ++ph) {
+      if (ph > 0) {
+        __syncthreads();                                                      // the previous phase's flush has read the pool
+        stage_phase(ph);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      if (fixed_ok) {
+        [&]<int... Ls>(std::integer_sequence<int, Ls...>) {
+          ([&] { if (!(PCT_BCOL_KO & 16) && phase_of[Ls] == ph) dots_lds(std::integral_constant<int, Ls>{}); }(), ...);
+        }(std::make_integer_sequence<int, L>{});
+        __syncthreads();                                                      // (B2) every wave is done with the values
+        int used = 0;
+#pragma unroll
+        for (int l = 0; l < L; ++l) used += phase_of[l] == ph ? wsize[l] : 0;
+        {
+          const col_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          for (int i = tid; i * 4 < used; i += BLOCK) *reinterpret_cast<col_f32x4 *>(pool + (size_t)i * 16) = z;   // counts
+#pragma unroll
+          for (int p = 0; p < 8; ++p)
+            for (int i = tid; i * 2 < used; i += BLOCK)
+              *reinterpret_cast<col_f32x4 *>(pool + BCOL_CNT_BYTES + (size_t)p * BCOL_PLANE_BYTES + (size_t)i * 16) = z;
+        }
+        __syncthreads();                                                      // (B3) accumulators zeroed
+        [&]<int... Ls>(std::integer_sequence<int, Ls...>) {
+          ([&] { if (!(PCT_BCOL_KO & 32) && phase_of[Ls] == ph) scatter_lds(std::integral_constant<int, Ls>{}); }(), ...);
+        }(std::make_integer_sequence<int, L>{});
+        __syncthreads();                                                      // (B4) every add of this phase is in the pool
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+          if (phase_of[l] == ph) flush_window(l);
+      }
+    }
+    [&]<int... Ls>(std::integer_sequence<int, Ls...>) {
+      ([&] { if (!(PCT_BCOL_KO & 8) && (phase_of[Ls] < 0 || !fixed_ok)) level_global(std::integral_constant<int, Ls>{}); }(), ...);
+    }(std::make_integer_sequence<int, L>{});
+
+    // ---- grad_sampling_loc (128 B) and grad_attn_weight (64 B) records; an idle lane's go out of the descriptor's range -----
+    {
+      const auto rsl = __builtin_amdgcn_make_buffer_rsrc(grad_loc + (long long)b * S * M * (L * P * 2), 0,
+                                                         (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 8)), RSRC_FLAGS);
+      const auto rsa = __builtin_amdgcn_make_buffer_rsrc(grad_attn + (long long)b * S * M * (L * P), 0,
+                                                         (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 4)), RSRC_FLAGS);
+      const unsigned dead = (unsigned)(qv >> 31) & 0x80000000u;
+      const unsigned ol = (rec_index(qv, m) * (unsigned)(L * P * 8)) | dead;
+      const unsigned oa = (rec_index(qv, m) * (unsigned)(L * P * 4)) | dead;
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const col_f32x4 x0 = {gl[l][0][0], gl[l][0][1], gl[l][1][0], gl[l][1][1]};
+        const col_f32x4 x1 = {gl[l][2][0], gl[l][2][1], gl[l][3][0], gl[l][3][1]};
+        const col_f32x4 xa = {ga[l][0], ga[l][1], ga[l][2], ga[l][3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(col_u32x4, x0), rsl, (int)(ol + l * 32), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(col_u32x4, x1), rsl, (int)(ol + l * 32 + 16), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(col_u32x4, xa), rsa, (int)(oa + l * 16), 0, 0);
+      }
+    }
+
+    item = item_n;
+    have = have_n;
+    b = b_n;
+    m = m_n;
+    qv = qv_n;
+  }
+}
+
+// ---- kernel choice for the backward (diagnostics; see include/pctrans_hip.h) ---------------------------------------------
+static std::atomic<int> g_bwd_choice{-1};                                    // -1: follow PCT_MSDA_BWD_KERNEL
+static std::atomic<int> g_bwd_last{0};
+void set_msda_bwd_kernel_choice(int c) { g_bwd_choice.store((c >= 0 && c <= 3) ? c : -1); }
+int msda_bwd_last_kernel() { return g_bwd_last.load(); }
+void note_msda_bwd_kernel(int k) { g_bwd_last.store(k); }
+int msda_bwd_kernel_choice()
+{
+  const int c = g_bwd_choice.load();
+  if (c >= 0) return c;
+  static const int env = [] {
+    const char *e = getenv("PCT_MSDA_BWD_KERNEL");
+    return !e ? 0 : (!strcmp(e, "win") ? 1 : (!strcmp(e, "generic") ? 2 : (!strcmp(e, "col") ? 3 : 0)));
+  }();
+  return env;
+}
+
+// returns -100 when this geometry is not covered (caller uses another kernel)
+int launch_msda_backward_col(const float *value, const int64_t *shapes, const int64_t *starts, const float *loc,
+                             const float *attn, const float *grad_out, int N, int S, int M, int D, int L, int Lq,
+                             int P, float *grad_value, float *grad_loc, float *grad_attn, bool forced, hipStream_t stream)
+{
+  if ((((uintptr_t)value | (uintptr_t)grad_out | (uintptr_t)loc | (uintptr_t)attn | (uintptr_t)grad_loc |
+        (uintptr_t)grad_attn) & 15u) || ((uintptr_t)grad_value & 3u))
+    return -100;
+  if (D != 16 || P != 4 || L < 3 || L > 5 || Lq != S || M < 1) return -100;
+  if ((long long)N * ((long long)S + 4096) * M >= 0x7fffffffLL) return -100;   // item / record arithmetic headroom
+  if ((long long)S * M * L * P * 8 >= 0x7fffffffLL) return -100;               // 32-bit byte offsets inside an image, all tensors
+  if ((long long)S * M * D * 4 >= 0x7fffffffLL) return -100;                   // (0x80000000 is the out-of-range sentinel)
+  if (S >= (1 << 24) || M >= (1 << 16)) return -100;                           // 24-bit multiplies in the record index
+  if (!forced && (long long)N * S * M < 160000) return -100;                   // too few columns to fill the persistent grid
+  const size_t lds = (size_t)BCOL_POOL_BYTES + BCOL_TAB_BYTES + ((size_t)(BCOL_BLOCK / 64) * (5 * 2 + 2) + 4) * sizeof(unsigned);
+  const dim3 grid(256 * 2), block(BCOL_BLOCK);
+  unsigned *queue = win_queue_slot(stream);                                    // nullptr: static item stride
+#define PCT_BCOL(L_)                                                                                                       \
+  do {                                                                                                                     \
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_backward_col_kernel<L_>),   \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
+    if (attr_rc != hipSuccess) return (int)attr_rc;                                                                        \
+    hipLaunchKernelGGL((msda_backward_col_kernel<L_>), grid, block, lds, stream, grad_out, value, shapes, starts, loc,     \
+                       attn, N, S, M, grad_value, grad_loc, grad_attn, queue);                                             \
+  } while (0)
+  if (L == 3) PCT_BCOL(3);
+  else if (L == 4) PCT_BCOL(4);
+  else PCT_BCOL(5);
+#undef PCT_BCOL
+  return (int)hipGetLastError();
+}
+
+}  // namespace pct

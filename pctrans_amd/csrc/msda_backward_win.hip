@@ -281,7 +281,13 @@ __global__ __launch_bounds__(WIN_BLOCK, 2) void msda_backward_win_kernel(
         const bool inside = y >= 0 && y < H && x >= 0 && x < W;
         const int gi = srcw[ch * GPX + px];
         const float g = (float)gi * inv_scale;
+#if defined(PCT_BWD_KO_FLUSH)      // timing experiments only (wrong results)
+        if (inside && gi == 0x12345678) unsafeAtomicAdd(glev + (long long)(y * W + x) * MD + ch, g);
+#elif defined(PCT_BWD_PLAIN_FLUSH)
+        if (inside && gi != 0) glev[(long long)(y * W + x) * MD + ch] = g;
+#else
         if (inside && gi != 0) unsafeAtomicAdd(glev + (long long)(y * W + x) * MD + ch, g);
+#endif
       }
     };
 #pragma unroll
@@ -421,6 +427,9 @@ __global__ __launch_bounds__(WIN_BLOCK, 2) void msda_backward_win_kernel(
             constexpr int MAGIC_BITS = 0x4B400000;
             // (element reads go through scalars: __builtin_bit_cast on an ext-vector element reads element 0)
             auto fx = [](float f) { return __float_as_int(f) - MAGIC_BITS; };
+#if defined(PCT_BWD_KO_LDSADD)
+            if (a1 == 0x7fffffff)
+#endif
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
               const float p0 = add1[e].x, p1 = add1[e].y, q0 = add2[e].x, q1 = add2[e].y;

@@ -113,4 +113,41 @@ __device__ __forceinline__ void block_box(const unsigned *rec, unsigned &lo, uns
   hi = ~(unsigned)__builtin_amdgcn_readfirstlane((int)b);
 }
 
+// ---- quad-cooperative record access ------------------------------------------------------------------------------------
+// A lane's records (128 B of sampling locations, 64 B of weights, 64 B of output per (query, head)) are 512 B - 1 KB apart
+// from its neighbours': loaded lane by lane, every 16-byte access of a wave instruction touches a different 128-byte line
+// and the texture-addresser serialises them (64 tag look-ups per instruction; measured: 16 K of the 77 K cycles an
+// item took, and everything behind it in the queue waits).  So the 4 lanes of a quad fetch 64 CONSECUTIVE bytes of ONE
+// record per instruction (16 look-ups), taking the quad's four records in turn, and the 4 x 4 block of 16-byte pieces is
+// transposed in registers: instruction s gives lane i piece (s - i) % 4 of record s; the lane rotates its four registers
+// by its own index (two layers of v_cndmask) and a quad_perm rotation by k delivers piece k of its own record.
+template <int K>
+__device__ __forceinline__ col_f32x4 quad_rot(const col_f32x4 v)      // lane c receives lane (c - K) % 4's value
+{
+  constexpr int ctrl = ((0 - K) & 3) | (((1 - K) & 3) << 2) | (((2 - K) & 3) << 4) | (((3 - K) & 3) << 6);
+  if constexpr (K == 0) return v;
+  return col_f32x4{dpp_f<ctrl>(v[0]), dpp_f<ctrl>(v[1]), dpp_f<ctrl>(v[2]), dpp_f<ctrl>(v[3])};
+}
+// x[k] <- x[(a + k) % 4] with the per-lane amount a = a0 + 2 * a1
+__device__ __forceinline__ void rot_regs(col_f32x4 (&x)[4], const bool a0, const bool a1)
+{
+  col_f32x4 t[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[k][e] = a0 ? x[(k + 1) & 3][e] : x[k][e];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[k][e] = a1 ? t[(k + 2) & 3][e] : t[k][e];
+}
+// in: x[s] = what this lane loaded for record s of its quad (piece (s - i) % 4); out: x[k] = piece k of its own record
+__device__ __forceinline__ void quad_transpose_in(col_f32x4 (&x)[4], const bool i0, const bool i1)
+{
+  rot_regs(x, i0, i1);
+  x[1] = quad_rot<1>(x[1]);
+  x[2] = quad_rot<2>(x[2]);
+  x[3] = quad_rot<3>(x[3]);
+}
+
 }  // namespace pct

@@ -6,7 +6,8 @@
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float *out, int iters, int stride)
 {
-  __shared__ float lds[16384];
+  __shared__ __attribute__((aligned(16))) float lds[16384];
+  unsigned long long *lds64 = reinterpret_cast<unsigned long long *>(lds);
   for (int i = threadIdx.x; i < 16384; i += 256) lds[i] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x;
@@ -24,6 +25,15 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, int stride)
         *(volatile float *)q = *(volatile float *)q + v;
       } else if constexpr (MODE == 3) {
         v += __hip_atomic_fetch_add((__attribute__((address_space(3))) float *)q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if constexpr (MODE == 5) {      // 64-bit integer add: two 32-bit fields per instruction
+        __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned long long *)(lds64 + ((lane * stride) % 4096) + (u * 264) % 4096),
+                               (unsigned long long)lane * 0x100000001ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if constexpr (MODE == 6) {      // random 32-bit: lane -> pseudo-random dword
+        unsigned h = (unsigned)(lane * 2654435761u + u * 40503u + it * 97u);
+        __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned *)(lds + ((h >> 7) % 8192)), (unsigned)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if constexpr (MODE == 7) {      // random 64-bit
+        unsigned h = (unsigned)(lane * 2654435761u + u * 40503u + it * 97u);
+        __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned long long *)(lds64 + ((h >> 7) % 4096)), (unsigned long long)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else if constexpr (MODE == 4) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         h2 hv = {(_Float16)1.0f, (_Float16)2.0f};
@@ -70,6 +80,10 @@ int main()
     run<2>("read+add+write", 1, wg);
     run<3>("ds_add_rtn_f32", 1, wg);
     run<4>("ds_pk_add_f16", 1, wg);
+    run<5>("ds_add_u64", 1, wg);
+    run<5>("ds_add_u64", 16, wg);
+    run<6>("ds_add_u32 random", 1, wg);
+    run<7>("ds_add_u64 random", 1, wg);
   }
   return 0;
 }
