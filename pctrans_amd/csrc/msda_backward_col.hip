@@ -23,14 +23,18 @@
 //     contributions cannot overflow; non-finite bounds send the item down the direct float path;
 //   * one coalesced flush per window: two global float atomics per (texel, channel pair) with n > 0, lanes on
 //     consecutive dwords;
-//   * the two passes share one pool (values, then accumulators), so a workgroup holds 1080 window pixels in 74 KB: the four
+//   * the two passes share one pool (values, then accumulators), so a workgroup holds 1092 window pixels in 74 KB: the four
 //     windows of a column with model-like offsets (~1 300 px) take two phases, the reference's init-like ones a single one;
-//   * levels whose box exceeds the pool use the direct path (global gathers + float atomics, reference summation order).
+//   * levels whose box exceeds the pool (and items whose bounds are not finite) are only FLAGGED here -- one byte per item --
+//     and a second launch of the same template (DIRECT) walks the items, skips those with an empty mask and does the
+//     flagged levels on the direct path (global gathers + float atomics, the reference's summation order).  Inlined into
+//     the main kernel that cold path cost 120 spilled registers whose reloads sat in the per-item planning.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
 #include <utility>
 
 #include "msda_col_common.hpp"
@@ -42,13 +46,14 @@ namespace pct {
 #endif
 
 constexpr int BCOL_BLOCK = 256;
-constexpr int BCOL_GPX = 1080;                                  // pixels per pool (= 24 mod 32: the flush's plane reads spread over the banks)
+constexpr int BCOL_GPX = 1092;                                  // pixels per pool (= 4 mod 32: the 8 planes of one pixel start 8 banks apart)
 constexpr int BCOL_CNT_BYTES = BCOL_GPX * 4;                    // contribution counts, one dword per pixel
 constexpr int BCOL_PLANE_BYTES = BCOL_GPX * 8;                  // one channel-pair plane of 64-bit accumulators
 constexpr int BCOL_POOL_BYTES = (BCOL_CNT_BYTES + 8 * BCOL_PLANE_BYTES + 63) & ~63;   // >= BCOL_GPX * 64 (the value windows)
 constexpr int BCOL_TAB_BYTES = 4096;                            // cell tables
 static_assert(BCOL_POOL_BYTES >= BCOL_GPX * 64, "value windows must fit the pool");
 static_assert(BCOL_CNT_BYTES + 7 * BCOL_PLANE_BYTES + 8 < 65536, "ds immediate offsets");
+static_assert((BCOL_PLANE_BYTES / 4) % 64 == 8, "plane stride in banks");
 
 template <int L>
 __host__ __device__ constexpr int bcol_level_of_step(const int ll)   // finest, coarsest, then the middle levels (as the forward)
@@ -56,12 +61,12 @@ __host__ __device__ constexpr int bcol_level_of_step(const int ll)   // finest, 
   return ll == 0 ? L - 1 : (ll == 1 ? 0 : L - ll);
 }
 
-template <int L>
+template <int L, bool DIRECT>
 __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn, const int N,
     const int S, const int M, float *__restrict__ grad_value, float *__restrict__ grad_loc,
-    float *__restrict__ grad_attn, unsigned *__restrict__ queue)
+    float *__restrict__ grad_attn, unsigned *__restrict__ queue, unsigned char *__restrict__ flags, const int flag_cap)
 {
   constexpr int P = 4, D = 16, PXB = 64, BLOCK = BCOL_BLOCK, NW = BLOCK / 64;
   static_assert(L >= 1 && L <= 5, "unsupported geometry");
@@ -165,12 +170,18 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
   int qi = lane & 3;
   const bool qi0 = qi & 1, qi1 = qi & 2;
   const unsigned rho = (unsigned)(lane >> 3) & 3u;                             // rotation of a head-pixel's 16-byte pieces
-  unsigned rot[4], prot[4];
+  unsigned rot[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    rot[j] = ((j + rho) & 3u) << 4;                                            // byte offset of the piece register j reads
-    prot[j] = (unsigned)BCOL_CNT_BYTES + ((j + rho) & 3u) * (unsigned)(2 * BCOL_PLANE_BYTES);   // ... and its first accumulator plane
-  }
+  for (int j = 0; j < 4; ++j) rot[j] = ((j + rho) & 3u) << 4;                  // byte offset of the piece register j reads
+  // The scatter's own rotations.  Many queries of a column hit the SAME texel of a coarse level in the same instruction
+  // (8 x 8 queries of the 128^2 level share one pixel of the 16^2 level: the 8 neighbours of a lane row and the wave's 4
+  // rows), and same-address LDS atomics are served one lane per clock (measured: 21 cycles per ds_add_u64 on average
+  // instead of 6.4).  So step t of lane i adds channel pair (t + i) % 8 -- eight row neighbours, eight different planes --
+  // and the lane rows (lane / 16) take a level's four points in rotated order -- four rows, four different samples.
+  const unsigned r8 = (unsigned)lane & 7u, srot = (unsigned)(lane >> 4) & 3u;
+  unsigned poff[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) poff[t] = (unsigned)BCOL_CNT_BYTES + ((t + r8) & 7u) * (unsigned)BCOL_PLANE_BYTES;
 
   const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int chunk = (items + 7) / 8;
@@ -246,6 +257,170 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
         raw[g][s4] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off[s4] + g * 64), 0, 0));
   };
 
+  // ---- pieces shared by the main kernel and the DIRECT one ------------------------------------------------------------------
+  // the record -> pixel coordinates (w_im, h_im) = loc * (W, H) - 0.5 (cuh:283-288) with the gate of cuh:290-296 folded in as
+  // in the forward: a coordinate that fails its test (NaN included) moves to -2, one past the map to W; the staged window
+  // carries a zero apron of two pixels, so such a sample reads zeros (all its gradients are exactly 0 for finite grad_out)
+  // and adds into apron accumulators that are never flushed
+  auto form_lxy = [&](col_f32x4 (&raw_)[NGL][4], col_f32x2 (&lxy_)[L][P]) {
+#pragma unroll
+    for (int g = 0; g < NGL; ++g) quad_transpose_in(raw_[g], qi0, qi1);
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int k = 0; k < P; ++k) {
+        const col_f32x4 pc = raw_[(l * 2 + k / 2) / 4][(l * 2 + k / 2) & 3];
+        const col_f32x2 v = {pc[(k & 1) * 2], pc[(k & 1) * 2 + 1]};
+        const col_f32x2 px = __builtin_elementwise_fma(v, fWH[l], col_f32x2{-0.5f, -0.5f});
+        lxy_[l][k][0] = fminf(px[0] > -1.f ? px[0] : -2.f, fWH[l][0]);
+        lxy_[l][k][1] = fminf(px[1] > -1.f ? px[1] : -2.f, fWH[l][1]);
+      }
+  };
+  // an item's weights and grad_output rows, quad-cooperatively
+  auto load_wg = [&](const int b_, const unsigned own_, col_f32x4 (&wraw_)[NGW][4], col_f32x4 (&graw_)[4]) {
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(attn + (long long)b_ * S * M * (L * P)), 0,
+                                                       (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 4)), RSRC_FLAGS);
+    const auto rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(grad_out + (long long)b_ * S * MD), 0,
+                                                       (int)((unsigned)S * (unsigned)MD * 4u), RSRC_FLAGS);
+    unsigned off[4], ofg[4];
+    quad_offsets(own_ * (unsigned)(L * P * 4), off);
+    quad_offsets(own_ * (unsigned)(D * 4), ofg);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+      for (int g = 0; g < NGW; ++g)
+        wraw_[g][s4] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)(off[s4] + g * 64), 0, 0));
+      graw_[s4] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, (int)ofg[s4], 0, 0));
+    }
+  };
+  // ... transposed; grad_output rotated like the head-pixel pieces (register j: piece (j + rho) % 4); an idle lane's are zero
+  auto front = [&](col_f32x4 (&wraw_)[NGW][4], col_f32x4 (&graw_)[4], const bool idle_, float (&wts_)[L][P],
+                   col_f32x2 (&go2_)[4][2]) {
+#pragma unroll
+    for (int g = 0; g < NGW; ++g) quad_transpose_in(wraw_[g], qi0, qi1);
+    quad_transpose_in(graw_, qi0, qi1);
+    rot_regs(graw_, rho & 1u, rho & 2u);
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int k = 0; k < P; ++k) wts_[l][k] = idle_ ? 0.f : wraw_[l / 4][l & 3][k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) go2_[j][e >> 1][e & 1] = idle_ ? 0.f : graw_[j][e];
+  };
+  // grad_sampling_loc (128 B) and grad_attn_weight (64 B) records are written level by level as soon as a level's results
+  // exist (48 result registers would otherwise live through the item); an idle lane's stores go out of the descriptors' range
+  auto store_level = [&](const int b_, const unsigned own_, const int qv_, const int l, const float (&ga)[P],
+                         const col_f32x2 (&gl)[P]) {
+    const auto rsl = __builtin_amdgcn_make_buffer_rsrc(grad_loc + (long long)b_ * S * M * (L * P * 2), 0,
+                                                       (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 8)), RSRC_FLAGS);
+    const auto rsa = __builtin_amdgcn_make_buffer_rsrc(grad_attn + (long long)b_ * S * M * (L * P), 0,
+                                                       (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 4)), RSRC_FLAGS);
+    const unsigned dead = (unsigned)(qv_ >> 31) & 0x80000000u;
+    const unsigned ol = (own_ * (unsigned)(L * P * 8)) | dead, oa = (own_ * (unsigned)(L * P * 4)) | dead;
+    const col_f32x4 x0 = {gl[0][0], gl[0][1], gl[1][0], gl[1][1]};
+    const col_f32x4 x1 = {gl[2][0], gl[2][1], gl[3][0], gl[3][1]};
+    const col_f32x4 xa = {ga[0], ga[1], ga[2], ga[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(col_u32x4, x0), rsl, (int)(ol + l * 32), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(col_u32x4, x1), rsl, (int)(ol + l * 32 + 16), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(col_u32x4, xa), rsa, (int)(oa + l * 16), 0, 0);
+  };
+
+  // More items than the flag buffer holds (the host cannot know: the level shapes live in device memory; it takes a pyramid
+  // of thousands of tiny columns): the main launch does nothing and the DIRECT one does every level of every item.
+  const bool overflow = items > flag_cap;
+  if constexpr (!DIRECT) {
+    if (overflow) return;
+  }
+  if constexpr (DIRECT) {
+    // ---- the DIRECT launch: flagged levels only, global gathers + float atomics, the reference's summation order -----------
+    for (int it = blockIdx.x; it < items; it += (int)gridDim.x) {
+      const unsigned mask = overflow ? (1u << L) - 1u : (unsigned)__builtin_amdgcn_readfirstlane((int)flags[it]);
+      if (mask == 0u) continue;
+      int b, m, qv;
+      decode(it, b, m, qv);
+      const unsigned own = rec_index(qv, m);
+      const bool idle = qv < 0;
+      col_f32x4 raw[NGL][4], wraw[NGW][4], graw[4];
+      issue_loc(b, m, qv, raw);
+      load_wg(b, own, wraw, graw);
+      col_f32x2 lxy[L][P], go2[4][2];
+      float wts[L][P];
+      form_lxy(raw, lxy);
+      front(wraw, graw, idle, wts, go2);
+      const float *vimg = value + (long long)b * S * MD + m * D;
+      float *gimg = grad_value + (long long)b * S * MD + m * D;
+      [&]<int... Ls>(std::integer_sequence<int, Ls...>) {
+        ([&] {
+          constexpr int l = Ls;
+          if (!((mask >> l) & 1u)) return;
+          const int H = Hs[l], W = Ws[l];
+          float ga[P];
+          col_f32x2 gl[P];
+          [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+            ([&] {
+              constexpr int k = Ks;
+              asm volatile("" : "+v"(lxy[l][k]));
+              const col_f32x2 pix = lxy[l][k];
+              const int x0 = cvt_flr(pix[0]), y0 = cvt_flr(pix[1]);                // inside [-2, W] x [-2, H]
+              const float lw = __builtin_amdgcn_fractf(pix[0]), lh = __builtin_amdgcn_fractf(pix[1]);
+              const float hw = 1.f - lw, hh = 1.f - lh;
+              const bool top = (unsigned)y0 < (unsigned)H, bot = (unsigned)(y0 + 1) < (unsigned)H;
+              const bool lft = (unsigned)x0 < (unsigned)W, rgt = (unsigned)(x0 + 1) < (unsigned)W;
+              const bool ok[4] = {top && lft, top && rgt, bot && lft, bot && rgt};
+              const long long e0 = (long long)(St[l] + y0 * W + x0) * MD;
+              const long long eo[4] = {e0, e0 + MD, e0 + (long long)W * MD, e0 + (long long)W * MD + MD};
+              const float wc[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+              const float aw = wts[l][k];
+              float s_a = 0.f, s_w = 0.f, s_h = 0.f;
+              const bool any = !idle && (ok[0] || ok[1] || ok[2] || ok[3]);
+              if (any) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const int ch0 = (int)(((unsigned)j + rho) & 3u) * 4;
+                  col_f32x4 v[4];
+#pragma unroll
+                  for (int c = 0; c < 4; ++c)
+                    v[c] = ok[c] ? *reinterpret_cast<const col_f32x4 *>(vimg + eo[c] + ch0) : col_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const float g = go2[j][e >> 1][e & 1];
+                    const float tgv = g * aw;                                      // top_grad_value (cuh:112)
+                    float gh = -(hw * v[0][e]);
+                    gh = fmaf(-lw, v[1][e], gh);
+                    gh = fmaf(hw, v[2][e], gh);
+                    gh = fmaf(lw, v[3][e], gh);
+                    float gw = -(hh * v[0][e]);
+                    gw = fmaf(hh, v[1][e], gw);
+                    gw = fmaf(-lh, v[2][e], gw);
+                    gw = fmaf(lh, v[3][e], gw);
+                    float val = wc[0] * v[0][e];
+                    val = fmaf(wc[1], v[1][e], val);
+                    val = fmaf(wc[2], v[2][e], val);
+                    val = fmaf(wc[3], v[3][e], val);
+                    s_a = fmaf(g, val, s_a);
+                    s_w = fmaf(gw, tgv, s_w);
+                    s_h = fmaf(gh, tgv, s_h);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                      if (ok[c]) unsafeAtomicAdd(gimg + eo[c] + ch0 + e, wc[c] * tgv);
+                  }
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+              ga[k] = any ? s_a : 0.f;
+              gl[k][0] = any ? s_w * fWH[l][0] : 0.f;
+              gl[k][1] = any ? s_h * fWH[l][1] : 0.f;
+            }(), ...);
+          }(std::make_integer_sequence<int, P>{});
+          store_level(b, own, qv, l, ga, gl);
+        }(), ...);
+      }(std::make_integer_sequence<int, L>{});
+    }
+    return;
+  }
+
   int item = xcd * chunk + slot0;
   bool have = item < item_end;
   int b = 0, m = 0, qv = 0;
@@ -262,25 +437,8 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
     const unsigned own = rec_index(qv, m);                                    // this lane's record: query * M + head
     const bool idle = qv < 0;
 
-    // ---- the record: pixel coordinates (w_im, h_im) = loc * (W, H) - 0.5 (cuh:283-288) with the gate of cuh:290-296 folded
-    // in as in the forward: a coordinate that fails its test (NaN included) moves to -2, one past the map to W; the staged
-    // window carries a zero apron of two pixels, so such a sample reads zeros (all its gradients are exactly 0 for finite
-    // grad_out) and adds into apron accumulators that are never flushed.
     col_f32x2 lxy[L][P];
-    {
-#pragma unroll
-      for (int g = 0; g < NGL; ++g) quad_transpose_in(raw[g], qi0, qi1);
-#pragma unroll
-      for (int l = 0; l < L; ++l)
-#pragma unroll
-        for (int k = 0; k < P; ++k) {
-          const col_f32x4 pc = raw[(l * 2 + k / 2) / 4][(l * 2 + k / 2) & 3];
-          const col_f32x2 v = {pc[(k & 1) * 2], pc[(k & 1) * 2 + 1]};
-          const col_f32x2 px = __builtin_elementwise_fma(v, fWH[l], col_f32x2{-0.5f, -0.5f});
-          lxy[l][k][0] = fminf(px[0] > -1.f ? px[0] : -2.f, fWH[l][0]);
-          lxy[l][k][1] = fminf(px[1] > -1.f ? px[1] : -2.f, fWH[l][1]);
-        }
-    }
+    form_lxy(raw, lxy);
 
     // ---- pre-pass: per-level bounding box (the forward's) ---------------------------------------------------------------
 #pragma unroll
@@ -296,22 +454,7 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
     }
     // ---- this item's weights and grad_output rows (quad-cooperative, looked at after the staging is issued) ----------------
     col_f32x4 wraw[NGW][4], graw[4];
-    {
-      const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(attn + (long long)b * S * M * (L * P)), 0,
-                                                         (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 4)), RSRC_FLAGS);
-      const auto rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(grad_out + (long long)b * S * MD), 0,
-                                                         (int)((unsigned)S * (unsigned)MD * 4u), RSRC_FLAGS);
-      unsigned off[4], ofg[4];
-      quad_offsets(own * (unsigned)(L * P * 4), off);
-      quad_offsets(own * (unsigned)(D * 4), ofg);
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-#pragma unroll
-        for (int g = 0; g < NGW; ++g)
-          wraw[g][s4] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)(off[s4] + g * 64), 0, 0));
-        graw[s4] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, (int)ofg[s4], 0, 0));
-      }
-    }
+    load_wg(b, own, wraw, graw);
     if (tid == 0) {
       unsigned fetched = (unsigned)(item - xcd * chunk + nslots);             // static stride when there is no queue
       if (queue) {
@@ -408,27 +551,19 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
     float wts[L][P];
     col_f32x2 go2[4][2];                                                       // register j: channels of piece (j + rho) % 4
     {
-#pragma unroll
-      for (int g = 0; g < NGW; ++g) quad_transpose_in(wraw[g], qi0, qi1);
-      quad_transpose_in(graw, qi0, qi1);
-      rot_regs(graw, rho & 1u, rho & 2u);
+      front(wraw, graw, idle, wts, go2);
       unsigned gmax = 0u, amax = 0u;                                           // |x| as bits: Inf / NaN compare largest
 #pragma unroll
       for (int l = 0; l < L; ++l)
 #pragma unroll
-        for (int k = 0; k < P; ++k) {
-          wts[l][k] = idle ? 0.f : wraw[l / 4][l & 3][k];
-          amax = max(amax, __float_as_uint(wts[l][k]) & 0x7fffffffu);
-        }
+        for (int k = 0; k < P; ++k) amax = max(amax, __float_as_uint(wts[l][k]) & 0x7fffffffu);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float gv = idle ? 0.f : graw[j][e];
-          gmax = max(gmax, __float_as_uint(gv) & 0x7fffffffu);
-          go2[j][e >> 1][e & 1] = gv;
+        for (int e = 0; e < 2; ++e) {
+          gmax = max(gmax, __float_as_uint(go2[j][e][0]) & 0x7fffffffu);
+          gmax = max(gmax, __float_as_uint(go2[j][e][1]) & 0x7fffffffu);
         }
-      }
       gmax = wave_reduce_umax(gmax);
       amax = wave_reduce_umax(amax);
       if (lane == 0) {
@@ -459,21 +594,11 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
       scale = uni(ldexpf(1.f, shift));
       inv_scale = uni(ldexpf(1.f, -shift));
     }
-    if (have_n) issue_loc(b_n, m_n, qv_n, raw);                               // in flight until the next iteration
-
-    float ga[L][P];
-    col_f32x2 gl[L][P];
-#pragma unroll
-    for (int l = 0; l < L; ++l)
-#pragma unroll
-      for (int k = 0; k < P; ++k) {
-        ga[l][k] = 0.f;
-        gl[l][k] = col_f32x2{0.f, 0.f};
-      }
-
     // ---- pass 1 of a level from its LDS window: four dot products per sample ---------------------------------------------
     auto dots_lds = [&](auto lc) {
       constexpr int l = decltype(lc)::value;
+      float ga[P];
+      col_f32x2 gl[P];
       [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
         ([&] {
           constexpr int k = Ks;
@@ -513,27 +638,40 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
             __builtin_amdgcn_sched_barrier(0);
           }
           // cuh:115-163 with the channel sums taken first: d_c = <grad_out, v_c>
-          ga[l][k] = hh * (hw * d[0] + lw * d[1]) + lh * (hw * d[2] + lw * d[3]);
-          const float aw = wts[l][k];
-          gl[l][k][0] = aw * fWH[l][0] * (hh * (d[1] - d[0]) + lh * (d[3] - d[2]));
-          gl[l][k][1] = aw * fWH[l][1] * (hw * (d[2] - d[0]) + lw * (d[3] - d[1]));
+          ga[k] = hh * (hw * d[0] + lw * d[1]) + lh * (hw * d[2] + lw * d[3]);
+          // (opaque: the products aw * (W, H) do not depend on the phase, and hoisted out of the phase loop they were 32
+          // registers, spilled and reloaded once per sample)
+          float aw = wts[l][k];
+          asm volatile("" : "+v"(aw));
+          gl[k][0] = aw * fWH[l][0] * (hh * (d[1] - d[0]) + lh * (d[3] - d[2]));
+          gl[k][1] = aw * fWH[l][1] * (hw * (d[2] - d[0]) + lw * (d[3] - d[1]));
         }(), ...);
       }(std::make_integer_sequence<int, P>{});
+      store_level(b, own, qv, l, ga, gl);
     };
     // ---- pass 2: round(w_c * attn * grad_out * scale) of two channels per 64-bit add, one count per corner ---------------
-    auto scatter_lds = [&](auto lc) {
+    auto scatter_impl = [&](auto lc, const col_f32x2 (&gor)[8]) {
       constexpr int l = decltype(lc)::value;
       const col_f32x2 magic2 = {12582912.f, 12582912.f};                      // 1.5 * 2^23
       [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
         ([&] {
           constexpr int k = Ks;
-          asm volatile("" : "+v"(lxy[l][k]));
-          const col_f32x2 pix = lxy[l][k];
+          // this lane row's point of step k (see srot above): (k + srot) % 4
+          const unsigned idx = ((unsigned)k + srot) & 3u;
+          const bool i0 = idx & 1u, i1 = idx & 2u;
+          auto sel4 = [&](const float a0, const float a1, const float a2, const float a3) {
+            const float lo = i0 ? a1 : a0, hi = i0 ? a3 : a2;
+            return i1 ? hi : lo;
+          };
+          col_f32x2 pix = {sel4(lxy[l][0][0], lxy[l][1][0], lxy[l][2][0], lxy[l][3][0]),
+                           sel4(lxy[l][0][1], lxy[l][1][1], lxy[l][2][1], lxy[l][3][1])};
+          float aw = sel4(wts[l][0], wts[l][1], wts[l][2], wts[l][3]);
+          asm volatile("" : "+v"(pix), "+v"(aw));
           const int x0 = cvt_flr(pix[0]), y0 = cvt_flr(pix[1]);
           const float lw = __builtin_amdgcn_fractf(pix[0]), lh = __builtin_amdgcn_fractf(pix[1]);
-          const float as = wts[l][k] * scale;
-          const col_f32x2 t = col_f32x2{1.f - lw, lw} * col_f32x2{as, as};
-          const col_f32x2 g12 = t * col_f32x2{1.f - lh, 1.f - lh}, g34 = t * col_f32x2{lh, lh};
+          const float as = aw * scale;
+          const col_f32x2 t2 = col_f32x2{1.f - lw, lw} * col_f32x2{as, as};
+          const col_f32x2 g12 = t2 * col_f32x2{1.f - lh, 1.f - lh}, g34 = t2 * col_f32x2{lh, lh};
           const unsigned pidx = (unsigned)(__mul24(y0, wwid[l]) + x0 + woff[l]);
           if (!(PCT_BCOL_KO & 1)) {
             lds_u32 *cp = (lds_u32 *)(pool + pidx * 4u);
@@ -549,23 +687,19 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
             const col_f32x2 wa = r ? col_f32x2{g34[0], g34[0]} : col_f32x2{g12[0], g12[0]};
             const col_f32x2 wb = r ? col_f32x2{g34[1], g34[1]} : col_f32x2{g12[1], g12[1]};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              unsigned char *pp = pool + (pr + prot[j]);
-#pragma unroll
-              for (int e = 0; e < 2; ++e) {
-                const col_f32x2 xa = __builtin_elementwise_fma(wa, go2[j][e], magic2);
-                const col_f32x2 xb = __builtin_elementwise_fma(wb, go2[j][e], magic2);
-                if (!(PCT_BCOL_KO & 1)) {
-                  lds_u64 *q = (lds_u64 *)(pp + e * BCOL_PLANE_BYTES);
-                  __hip_atomic_fetch_add(q, __builtin_bit_cast(unsigned long long, xa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                  __hip_atomic_fetch_add(q + 1, __builtin_bit_cast(unsigned long long, xb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else {
-                  asm volatile("" ::"v"(xa), "v"(xb));
-                }
+            for (int t = 0; t < 8; ++t) {
+              const col_f32x2 xa = __builtin_elementwise_fma(wa, gor[t], magic2);
+              const col_f32x2 xb = __builtin_elementwise_fma(wb, gor[t], magic2);
+              if (!(PCT_BCOL_KO & 1)) {
+                lds_u64 *q = (lds_u64 *)(pool + (pr + poff[t]));
+                __hip_atomic_fetch_add(q, __builtin_bit_cast(unsigned long long, xa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(q + 1, __builtin_bit_cast(unsigned long long, xb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              } else {
+                asm volatile("" ::"v"(xa), "v"(xb));
               }
               // (without the fence the compiler forms the 64 packed products of a sample -- of several samples -- first
               // and spills them on the way to the adds)
-              __builtin_amdgcn_sched_barrier(0);
+              if (t & 1) __builtin_amdgcn_sched_barrier(0);
             }
           }
         }(), ...);
@@ -573,93 +707,39 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
     };
     // ---- flush of one window: (T, n) -> the two 32-bit sums -> two float atomics per (texel, channel pair) with n > 0 -------
     auto flush_window = [&](const int l) {
-      const float inv_w = 1.0f / (float)wwid[l];
-      const int n8 = wsize[l] * 8;
-      float *glev = gimg + (long long)St[l] * MD;
+      // a wave takes every NW-th window row; one wave instruction covers 8 pixels x 8 channel pairs (lanes on consecutive
+      // dwords of grad_value: 512 contiguous bytes); rows and columns outside the map (the apron) are skipped
       const int H = Hs[l], W = Ws[l];
-      for (int i = tid; i < n8; i += BLOCK) {
-        const int px = i >> 3, pair = i & 7;
-        const int r = (int)(((float)px + 0.5f) * inv_w);
-        const int y = wy0[l] + r, x = wx0[l] + px - r * wwid[l];
-        const bool inside = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        const unsigned n = *reinterpret_cast<const unsigned *>(pool + (size_t)(wbase[l] + px) * 4);
-        if (inside && n != 0u) {
-          const unsigned long long T = *reinterpret_cast<const unsigned long long *>(
-              pool + BCOL_CNT_BYTES + (size_t)pair * BCOL_PLANE_BYTES + (size_t)(wbase[l] + px) * 8);
-          constexpr unsigned K = 0x4B400000u;
-          const unsigned nK = n * K;
-          const int lo = (int)((unsigned)T - nK);
-          const unsigned long long U = (unsigned long long)n * K + (unsigned long long)(long long)lo;
-          const int hi = (int)((unsigned)(T >> 32) - (unsigned)(U >> 32) - nK);
-          float *dst = glev + (long long)(y * W + x) * MD + 2 * pair;
-          if (!(PCT_BCOL_KO & 4)) {
-            if (lo != 0) unsafeAtomicAdd(dst, (float)lo * inv_scale);
-            if (hi != 0) unsafeAtomicAdd(dst + 1, (float)hi * inv_scale);
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const int pair = lane & 7, dxl = lane >> 3;
+      float *glev = gimg + (long long)St[l] * MD + 2 * pair;
+      for (int r = wv; r < whgt[l]; r += NW) {
+        const int y = wy0[l] + r;
+        if ((unsigned)y >= (unsigned)H) continue;
+        const int rowi = wbase[l] + r * wwid[l];
+        float *grow = glev + (long long)y * W * MD;
+        for (int c0 = 0; c0 < wwid[l]; c0 += 8) {
+          const int xw = c0 + dxl, x = wx0[l] + xw;
+          if (xw < wwid[l] && (unsigned)x < (unsigned)W) {
+            const unsigned n = *reinterpret_cast<const unsigned *>(pool + (size_t)(rowi + xw) * 4);
+            if (n != 0u) {
+              const unsigned long long T = *reinterpret_cast<const unsigned long long *>(
+                  pool + BCOL_CNT_BYTES + (size_t)pair * BCOL_PLANE_BYTES + (size_t)(rowi + xw) * 8);
+              constexpr unsigned K = 0x4B400000u;
+              const unsigned nK = n * K;
+              const int lo = (int)((unsigned)T - nK);
+              const unsigned long long U = (unsigned long long)n * K + (unsigned long long)(long long)lo;
+              const int hi = (int)((unsigned)(T >> 32) - (unsigned)(U >> 32) - nK);
+              float *dst = grow + (long long)x * MD;
+              if (!(PCT_BCOL_KO & 4)) {
+                if (lo != 0) unsafeAtomicAdd(dst, (float)lo * inv_scale);
+                if (hi != 0) unsafeAtomicAdd(dst + 1, (float)hi * inv_scale);
+              }
+            }
           }
         }
       }
     };
-    // ---- a level on the direct path: global gathers, float atomics, the reference's summation order (cuh:104-163) ---------
-    auto level_global = [&](auto lc) {
-      constexpr int l = decltype(lc)::value;
-      const int H = Hs[l], W = Ws[l];
-      const float *vimg = value + (long long)b * S * MD + m * D;
-      [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
-        ([&] {
-          constexpr int k = Ks;
-          const col_f32x2 pix = lxy[l][k];
-          const int x0 = cvt_flr(pix[0]), y0 = cvt_flr(pix[1]);                // inside [-2, W] x [-2, H]
-          const float lw = __builtin_amdgcn_fractf(pix[0]), lh = __builtin_amdgcn_fractf(pix[1]);
-          const float hw = 1.f - lw, hh = 1.f - lh;
-          const bool top = (unsigned)y0 < (unsigned)H, bot = (unsigned)(y0 + 1) < (unsigned)H;
-          const bool lft = (unsigned)x0 < (unsigned)W, rgt = (unsigned)(x0 + 1) < (unsigned)W;
-          const bool ok[4] = {top && lft, top && rgt, bot && lft, bot && rgt};
-          const long long e0 = (long long)(St[l] + y0 * W + x0) * MD;
-          const long long eo[4] = {e0, e0 + MD, e0 + (long long)W * MD, e0 + (long long)W * MD + MD};
-          const float wc[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-          const float aw = wts[l][k];
-          float s_a = 0.f, s_w = 0.f, s_h = 0.f;
-          const bool any = !idle && (ok[0] || ok[1] || ok[2] || ok[3]);
-          if (any) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int ch0 = (int)(((unsigned)j + rho) & 3u) * 4;
-              col_f32x4 v[4];
-#pragma unroll
-              for (int c = 0; c < 4; ++c)
-                v[c] = ok[c] ? *reinterpret_cast<const col_f32x4 *>(vimg + eo[c] + ch0) : col_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float g = go2[j][e >> 1][e & 1];
-                const float tgv = g * aw;                                      // top_grad_value (cuh:112)
-                float gh = -(hw * v[0][e]);
-                gh = fmaf(-lw, v[1][e], gh);
-                gh = fmaf(hw, v[2][e], gh);
-                gh = fmaf(lw, v[3][e], gh);
-                float gw = -(hh * v[0][e]);
-                gw = fmaf(hh, v[1][e], gw);
-                gw = fmaf(-lh, v[2][e], gw);
-                gw = fmaf(lh, v[3][e], gw);
-                float val = wc[0] * v[0][e];
-                val = fmaf(wc[1], v[1][e], val);
-                val = fmaf(wc[2], v[2][e], val);
-                val = fmaf(wc[3], v[3][e], val);
-                s_a = fmaf(g, val, s_a);
-                s_w = fmaf(gw, tgv, s_w);
-                s_h = fmaf(gh, tgv, s_h);
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                  if (ok[c]) unsafeAtomicAdd(gimg + eo[c] + ch0 + e, wc[c] * tgv);
-              }
-            }
-          }
-          ga[l][k] = any ? s_a : 0.f;
-          gl[l][k][0] = any ? s_w * fWH[l][0] : 0.f;
-          gl[l][k][1] = any ? s_h * fWH[l][1] : 0.f;
-        }(), ...);
-      }(std::make_integer_sequence<int, P>{});
-    };
-
 #pragma unroll 1
     for (int ph = 0; ph < nph; ++ph) {
       if (ph > 0) {
@@ -673,6 +753,7 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
           ([&] { if (!(PCT_BCOL_KO & 16) && phase_of[Ls] == ph) dots_lds(std::integral_constant<int, Ls>{}); }(), ...);
         }(std::make_integer_sequence<int, L>{});
         __syncthreads();                                                      // (B2) every wave is done with the values
+        if (ph == nph - 1 && have_n) issue_loc(b_n, m_n, qv_n, raw);           // in flight until the next iteration
         int used = 0;
 #pragma unroll
         for (int l = 0; l < L; ++l) used += phase_of[l] == ph ? wsize[l] : 0;
@@ -685,6 +766,22 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
               *reinterpret_cast<col_f32x4 *>(pool + BCOL_CNT_BYTES + (size_t)p * BCOL_PLANE_BYTES + (size_t)i * 16) = z;
         }
         __syncthreads();                                                      // (B3) accumulators zeroed
+        col_f32x2 gor[8];                                                     // register t: channel pair (t + r8) % 8
+      // go2 holds pair (u + 2 * rho) % 8 in slot u = 2 * j + e; the scatter wants pair (t + r8) % 8 in register t: rotate by
+        // the remaining amount d = (r8 - 2 * rho) % 8 (three layers of selects, once per item)
+        {
+          const unsigned d = (r8 - 2u * rho) & 7u;
+          col_f32x2 a[8], c[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] = go2[u >> 1][u & 1];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) c[u] = (d & 1u) ? a[(u + 1) & 7] : a[u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] = (d & 2u) ? c[(u + 2) & 7] : c[u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) gor[u] = (d & 4u) ? a[(u + 4) & 7] : a[u];
+        }
+        auto scatter_lds = [&](auto lc) { scatter_impl(lc, gor); };
         [&]<int... Ls>(std::integer_sequence<int, Ls...>) {
           ([&] { if (!(PCT_BCOL_KO & 32) && phase_of[Ls] == ph) scatter_lds(std::integral_constant<int, Ls>{}); }(), ...);
         }(std::make_integer_sequence<int, L>{});
@@ -694,28 +791,13 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
           if (phase_of[l] == ph) flush_window(l);
       }
     }
-    [&]<int... Ls>(std::integer_sequence<int, Ls...>) {
-      ([&] { if (!(PCT_BCOL_KO & 8) && (phase_of[Ls] < 0 || !fixed_ok)) level_global(std::integral_constant<int, Ls>{}); }(), ...);
-    }(std::make_integer_sequence<int, L>{});
-
-    // ---- grad_sampling_loc (128 B) and grad_attn_weight (64 B) records; an idle lane's go out of the descriptor's range -----
-    {
-      const auto rsl = __builtin_amdgcn_make_buffer_rsrc(grad_loc + (long long)b * S * M * (L * P * 2), 0,
-                                                         (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 8)), RSRC_FLAGS);
-      const auto rsa = __builtin_amdgcn_make_buffer_rsrc(grad_attn + (long long)b * S * M * (L * P), 0,
-                                                         (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 4)), RSRC_FLAGS);
-      const unsigned dead = (unsigned)(qv >> 31) & 0x80000000u;
-      const unsigned ol = (rec_index(qv, m) * (unsigned)(L * P * 8)) | dead;
-      const unsigned oa = (rec_index(qv, m) * (unsigned)(L * P * 4)) | dead;
+    if ((nph == 0 || !fixed_ok) && have_n) issue_loc(b_n, m_n, qv_n, raw);
+    // levels this launch did not do: a level whose box exceeds the pool; every level of an item whose bounds are not finite
+    if (tid == 0) {
+      unsigned mask = fixed_ok ? 0u : (1u << L) - 1u;
 #pragma unroll
-      for (int l = 0; l < L; ++l) {
-        const col_f32x4 x0 = {gl[l][0][0], gl[l][0][1], gl[l][1][0], gl[l][1][1]};
-        const col_f32x4 x1 = {gl[l][2][0], gl[l][2][1], gl[l][3][0], gl[l][3][1]};
-        const col_f32x4 xa = {ga[l][0], ga[l][1], ga[l][2], ga[l][3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(col_u32x4, x0), rsl, (int)(ol + l * 32), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(col_u32x4, x1), rsl, (int)(ol + l * 32 + 16), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(col_u32x4, xa), rsa, (int)(oa + l * 16), 0, 0);
-      }
+      for (int l = 0; l < L; ++l) mask |= phase_of[l] < 0 ? 1u << l : 0u;
+      flags[item] = (unsigned char)mask;
     }
 
     item = item_n;
@@ -743,6 +825,43 @@ int msda_bwd_kernel_choice()
   return env;
 }
 
+// One byte per work item for the main launch to tell the DIRECT one which levels are left (see the header).  Buffers of
+// BCOL_FLAG_BYTES each, allocated once per device: a ring for eager launches (launches in flight together on different
+// streams must not share one) and a pool handed out once each to launches recorded into a HIP graph (the pointer is baked
+// in).  nullptr: no buffer to be had (first use under stream capture, pool exhausted) -> the caller falls back.  A launch
+// with more items than a buffer holds is dealt with inside the kernels (`overflow`).
+constexpr size_t BCOL_FLAG_BYTES = 1u << 20;
+static unsigned char *bcol_flag_buffer(hipStream_t stream)
+{
+  constexpr int MAX_DEV = 64, RING = 8, CAPTURE_POOL = 56;
+  static std::mutex mu;
+  static unsigned char *base[MAX_DEV] = {};
+  static unsigned seq[MAX_DEV] = {}, cap_used[MAX_DEV] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!base[dev]) {
+    if (capturing) return nullptr;                                              // (an allocation would invalidate the capture)
+    void *p = nullptr;
+    if (hipMalloc(&p, (size_t)(RING + CAPTURE_POOL) * BCOL_FLAG_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    base[dev] = static_cast<unsigned char *>(p);
+  }
+  if (capturing) {
+    if (cap_used[dev] >= (unsigned)CAPTURE_POOL) return nullptr;
+    return base[dev] + (size_t)(RING + cap_used[dev]++) * BCOL_FLAG_BYTES;
+  }
+  return base[dev] + (size_t)(seq[dev]++ % RING) * BCOL_FLAG_BYTES;
+}
+
 // returns -100 when this geometry is not covered (caller uses another kernel)
 int launch_msda_backward_col(const float *value, const int64_t *shapes, const int64_t *starts, const float *loc,
                              const float *attn, const float *grad_out, int N, int S, int M, int D, int L, int Lq,
@@ -757,16 +876,29 @@ int launch_msda_backward_col(const float *value, const int64_t *shapes, const in
   if ((long long)S * M * D * 4 >= 0x7fffffffLL) return -100;                   // (0x80000000 is the out-of-range sentinel)
   if (S >= (1 << 24) || M >= (1 << 16)) return -100;                           // 24-bit multiplies in the record index
   if (!forced && (long long)N * S * M < 160000) return -100;                   // too few columns to fill the persistent grid
+  unsigned char *flags = bcol_flag_buffer(stream);
+  if (!flags) return -100;
+  // (PCT_BCOL_FLAG_CAP: a smaller capacity, so that a test can reach the overflow route with an oracle-sized case)
+  static const int cap_env = [] { const char *e = getenv("PCT_BCOL_FLAG_CAP"); return e ? atoi(e) : 0; }();
+  const int flag_cap = (cap_env > 0 && cap_env < (int)BCOL_FLAG_BYTES) ? cap_env : (int)BCOL_FLAG_BYTES;
   const size_t lds = (size_t)BCOL_POOL_BYTES + BCOL_TAB_BYTES + ((size_t)(BCOL_BLOCK / 64) * (5 * 2 + 2) + 4) * sizeof(unsigned);
+  const size_t lds_direct = (size_t)BCOL_POOL_BYTES + BCOL_TAB_BYTES + 256;    // (same carve-up; only the tables are used)
   const dim3 grid(256 * 2), block(BCOL_BLOCK);
   unsigned *queue = win_queue_slot(stream);                                    // nullptr: static item stride
 #define PCT_BCOL(L_)                                                                                                       \
   do {                                                                                                                     \
-    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_backward_col_kernel<L_>),   \
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
+    static const hipError_t attr_rc = hipFuncSetAttribute(                                                                 \
+        reinterpret_cast<const void *>(&msda_backward_col_kernel<L_, false>), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+        160 * 1024);                                                                                                       \
+    static const hipError_t attr_rc2 = hipFuncSetAttribute(                                                                \
+        reinterpret_cast<const void *>(&msda_backward_col_kernel<L_, true>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+        160 * 1024);                                                                                                       \
     if (attr_rc != hipSuccess) return (int)attr_rc;                                                                        \
-    hipLaunchKernelGGL((msda_backward_col_kernel<L_>), grid, block, lds, stream, grad_out, value, shapes, starts, loc,     \
-                       attn, N, S, M, grad_value, grad_loc, grad_attn, queue);                                             \
+    if (attr_rc2 != hipSuccess) return (int)attr_rc2;                                                                      \
+    hipLaunchKernelGGL((msda_backward_col_kernel<L_, false>), grid, block, lds, stream, grad_out, value, shapes, starts,   \
+                       loc, attn, N, S, M, grad_value, grad_loc, grad_attn, queue, flags, flag_cap);                                 \
+    hipLaunchKernelGGL((msda_backward_col_kernel<L_, true>), grid, block, lds_direct, stream, grad_out, value, shapes,     \
+                       starts, loc, attn, N, S, M, grad_value, grad_loc, grad_attn, nullptr, flags, flag_cap);                       \
   } while (0)
   if (L == 3) PCT_BCOL(3);
   else if (L == 4) PCT_BCOL(4);

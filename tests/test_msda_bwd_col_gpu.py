@@ -190,3 +190,33 @@ def test_backward_auto_takes_the_column_kernel_at_model_batch(MSDA, lib):
     r2 = float((ga.double() * attn.double()).sum())
     ref = float((out.double().abs() * dev(go).double().abs()).sum())
     assert abs(lhs - r1) <= 1e-5 * ref and abs(lhs - r2) <= 1e-5 * ref, (lhs, r1, r2, ref)
+
+
+def test_backward_column_flag_overflow_route_matches():
+    """More work items than the flag buffer holds: the main launch declines inside the kernel and the DIRECT launch does
+    every level of every item (PCT_BCOL_FLAG_CAP shrinks the capacity so that an oracle-sized case gets there)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from msda_cases import make_case\n"
+        "from oracle import msda_oracle as orc\n"
+        "from pctrans_amd import MultiScaleDeformableAttention as MSDA, _lib\n"
+        "P1 = [(16, 16), (32, 32), (64, 64)]\n"
+        "c = make_case(seed=78, N=1, M=8, D=16, Lq=5376, P=4, shapes=P1, model_like=True)\n"
+        "go = np.random.RandomState(178).standard_normal((1, 5376, 128)).astype(np.float32)\n"
+        "dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()\n"
+        "_lib.lib().pct_msda_set_bwd_kernel_choice(3)\n"
+        "g = MSDA.ms_deform_attn_backward(dev(c['value']), dev(c['shapes']), dev(c['starts']), dev(c['loc']), dev(c['attn']), dev(go), 64)\n"
+        "torch.cuda.synchronize()\n"
+        "assert _lib.lib().pct_msda_last_bwd_kernel() == 3\n"
+        "w = orc.backward(c['value'], c['shapes'], c['starts'], c['loc'], c['attn'], go)\n"
+        "for a, b in ((g[0], w[0]), (g[2], w[2])):\n"
+        "    np.testing.assert_allclose(a.cpu().numpy(), b, rtol=0, atol=2e-5 * max(1.0, float(np.abs(b).max())))\n"
+        "print('ok')\n" % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, PCT_BCOL_FLAG_CAP="16")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
