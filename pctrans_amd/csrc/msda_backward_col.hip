@@ -42,7 +42,8 @@
 namespace pct {
 
 #ifndef PCT_BCOL_KO
-#define PCT_BCOL_KO 0         /* knock-outs (WRONG RESULTS, timing only): 1 = no scatter adds, 2 = no dots reads, 4 = no flush atomics */
+#define PCT_BCOL_KO 0         /* knock-outs (WRONG RESULTS, timing only): 1 = no scatter adds, 2 = no dots reads, 4 = no flush atomics,
+                                 16 = no dots pass, 32 = no scatter pass, 64 = no count adds, 128 = no zeroing */
 #endif
 
 constexpr int BCOL_BLOCK = 256;
@@ -334,7 +335,13 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
     if (overflow) return;
   }
   if constexpr (DIRECT) {
-    // ---- the DIRECT launch: flagged levels only, global gathers + float atomics, the reference's summation order -----------
+    // ---- the DIRECT launch: flagged levels only, global gathers + float atomics ----------------------------------------------
+    // The QUAD works on one member's sample at a time (as the forward's global-memory levels): the member's geometry is
+    // broadcast by DPP and lane c takes the 16-byte piece (s - c) % 4 of every corner -- the quad reads and atomically adds
+    // whole 64-byte head-pixels, 16 tag look-ups per wave instruction instead of 64 (lane by lane with all 16 channels the
+    // float atomics ran four times slower).  That piece of the member's grad_output row is exactly what the quad-cooperative
+    // load delivers before its transposition, so grad_output is not transposed at all.  Per channel the reference's
+    // summation order (cuh:104-163); the three channel sums of a sample are reduced across the quad afterwards.
     for (int it = blockIdx.x; it < items; it += (int)gridDim.x) {
       const unsigned mask = overflow ? (1u << L) - 1u : (unsigned)__builtin_amdgcn_readfirstlane((int)flags[it]);
       if (mask == 0u) continue;
@@ -342,13 +349,18 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
       decode(it, b, m, qv);
       const unsigned own = rec_index(qv, m);
       const bool idle = qv < 0;
-      col_f32x4 raw[NGL][4], wraw[NGW][4], graw[4];
+      col_f32x4 raw[NGL][4], wraw[NGW][4], gq[4];                              // gq[s]: piece (s - qi) % 4 of member s's grad_output
       issue_loc(b, m, qv, raw);
-      load_wg(b, own, wraw, graw);
-      col_f32x2 lxy[L][P], go2[4][2];
+      load_wg(b, own, wraw, gq);
+      col_f32x2 lxy[L][P];
       float wts[L][P];
       form_lxy(raw, lxy);
-      front(wraw, graw, idle, wts, go2);
+#pragma unroll
+      for (int g = 0; g < NGW; ++g) quad_transpose_in(wraw[g], qi0, qi1);
+#pragma unroll
+      for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int k = 0; k < P; ++k) wts[l][k] = wraw[l / 4][l & 3][k];
       const float *vimg = value + (long long)b * S * MD + m * D;
       float *gimg = grad_value + (long long)b * S * MD + m * D;
       [&]<int... Ls>(std::integer_sequence<int, Ls...>) {
@@ -364,54 +376,73 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
               asm volatile("" : "+v"(lxy[l][k]));
               const col_f32x2 pix = lxy[l][k];
               const int x0 = cvt_flr(pix[0]), y0 = cvt_flr(pix[1]);                // inside [-2, W] x [-2, H]
-              const float lw = __builtin_amdgcn_fractf(pix[0]), lh = __builtin_amdgcn_fractf(pix[1]);
-              const float hw = 1.f - lw, hh = 1.f - lh;
+              const float o_lw = __builtin_amdgcn_fractf(pix[0]), o_lh = __builtin_amdgcn_fractf(pix[1]);
               const bool top = (unsigned)y0 < (unsigned)H, bot = (unsigned)(y0 + 1) < (unsigned)H;
               const bool lft = (unsigned)x0 < (unsigned)W, rgt = (unsigned)(x0 + 1) < (unsigned)W;
-              const bool ok[4] = {top && lft, top && rgt, bot && lft, bot && rgt};
-              const long long e0 = (long long)(St[l] + y0 * W + x0) * MD;
-              const long long eo[4] = {e0, e0 + MD, e0 + (long long)W * MD, e0 + (long long)W * MD + MD};
-              const float wc[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-              const float aw = wts[l][k];
-              float s_a = 0.f, s_w = 0.f, s_h = 0.f;
-              const bool any = !idle && (ok[0] || ok[1] || ok[2] || ok[3]);
-              if (any) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  const int ch0 = (int)(((unsigned)j + rho) & 3u) * 4;
-                  col_f32x4 v[4];
-#pragma unroll
-                  for (int c = 0; c < 4; ++c)
-                    v[c] = ok[c] ? *reinterpret_cast<const col_f32x4 *>(vimg + eo[c] + ch0) : col_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) {
-                    const float g = go2[j][e >> 1][e & 1];
-                    const float tgv = g * aw;                                      // top_grad_value (cuh:112)
-                    float gh = -(hw * v[0][e]);
-                    gh = fmaf(-lw, v[1][e], gh);
-                    gh = fmaf(hw, v[2][e], gh);
-                    gh = fmaf(lw, v[3][e], gh);
-                    float gw = -(hh * v[0][e]);
-                    gw = fmaf(hh, v[1][e], gw);
-                    gw = fmaf(-lh, v[2][e], gw);
-                    gw = fmaf(lh, v[3][e], gw);
-                    float val = wc[0] * v[0][e];
-                    val = fmaf(wc[1], v[1][e], val);
-                    val = fmaf(wc[2], v[2][e], val);
-                    val = fmaf(wc[3], v[3][e], val);
-                    s_a = fmaf(g, val, s_a);
-                    s_w = fmaf(gw, tgv, s_w);
-                    s_h = fmaf(gh, tgv, s_h);
+              // valid corners as bits; none for an idle lane or a gated-out sample (the reference skips it: exact zeros)
+              const unsigned o_ok = idle ? 0u : ((top && lft ? 1u : 0u) | (top && rgt ? 2u : 0u) | (bot && lft ? 4u : 0u) | (bot && rgt ? 8u : 0u));
+              const int o_e0 = (St[l] + y0 * W + x0) * MD;                          // (launcher: S * M * D < 2^31)
+              const float o_aw = wts[l][k];
+              float pa[4], pw[4], ph[4];                                           // [member]: my 4 channels' share of its sums
+              [&]<int... Ss>(std::integer_sequence<int, Ss...>) {
+                ([&] {
+                  constexpr int s4 = Ss;
+                  constexpr int CT = BcastCtrl<4, s4>::value;
+                  const unsigned ok = dpp_u<CT>(o_ok);
+                  const int e0 = dpp_i<CT>(o_e0);
+                  const float lw = dpp_f<CT>(o_lw), lh = dpp_f<CT>(o_lh), aw = dpp_f<CT>(o_aw);
+                  float s_a = 0.f, s_w = 0.f, s_h = 0.f;
+                  if (ok != 0u) {
+                    const float hw = 1.f - lw, hh = 1.f - lh;
+                    const float wc[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+                    const int pc = ((s4 - qi) & 3) * 4;
+                    const int eo[4] = {e0 + pc, e0 + MD + pc, e0 + W * MD + pc, e0 + W * MD + MD + pc};
+                    col_f32x4 v[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                      if (ok[c]) unsafeAtomicAdd(gimg + eo[c] + ch0 + e, wc[c] * tgv);
+                      v[c] = ((ok >> c) & 1u) ? *reinterpret_cast<const col_f32x4 *>(vimg + eo[c]) : col_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                      const float g = gq[s4][e];
+                      const float tgv = g * aw;                                    // top_grad_value (cuh:112)
+                      float gh = -(hw * v[0][e]);
+                      gh = fmaf(-lw, v[1][e], gh);
+                      gh = fmaf(hw, v[2][e], gh);
+                      gh = fmaf(lw, v[3][e], gh);
+                      float gw = -(hh * v[0][e]);
+                      gw = fmaf(hh, v[1][e], gw);
+                      gw = fmaf(-lh, v[2][e], gw);
+                      gw = fmaf(lh, v[3][e], gw);
+                      float val = wc[0] * v[0][e];
+                      val = fmaf(wc[1], v[1][e], val);
+                      val = fmaf(wc[2], v[2][e], val);
+                      val = fmaf(wc[3], v[3][e], val);
+                      s_a = fmaf(g, val, s_a);
+                      s_w = fmaf(gw, tgv, s_w);
+                      s_h = fmaf(gh, tgv, s_h);
+#pragma unroll
+                      for (int c = 0; c < 4; ++c)
+                        if ((ok >> c) & 1u) unsafeAtomicAdd(gimg + eo[c] + e, wc[c] * tgv);
+                    }
                   }
+                  pa[s4] = s_a;
+                  pw[s4] = s_w;
+                  ph[s4] = s_h;
                   __builtin_amdgcn_sched_barrier(0);
-                }
-              }
-              ga[k] = any ? s_a : 0.f;
-              gl[k][0] = any ? s_w * fWH[l][0] : 0.f;
-              gl[k][1] = any ? s_h * fWH[l][1] : 0.f;
+                }(), ...);
+              }(std::make_integer_sequence<int, 4>{});
+              // lane i <- sum over the quad's lanes of their share of member i's sums (two exchange steps)
+              auto quad_reduce = [&](const float (&t)[4]) {
+                const float k0 = qi0 ? t[1] : t[0], g0 = qi0 ? t[0] : t[1];       // keep members of my parity, give the others
+                const float k1 = qi0 ? t[3] : t[2], g1 = qi0 ? t[2] : t[3];
+                const float u0 = k0 + dpp_f<0xB1>(g0), u1 = k1 + dpp_f<0xB1>(g1);  // quad_perm [1,0,3,2]
+                const float kk = qi1 ? u1 : u0, gg = qi1 ? u0 : u1;
+                return kk + dpp_f<0x4E>(gg);                                       // quad_perm [2,3,0,1]
+              };
+              const float r_a = quad_reduce(pa), r_w = quad_reduce(pw), r_h = quad_reduce(ph);
+              ga[k] = o_ok ? r_a : 0.f;
+              gl[k][0] = o_ok ? r_w * fWH[l][0] : 0.f;
+              gl[k][1] = o_ok ? r_h * fWH[l][1] : 0.f;
             }(), ...);
           }(std::make_integer_sequence<int, P>{});
           store_level(b, own, qv, l, ga, gl);
@@ -673,7 +704,7 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
           const col_f32x2 t2 = col_f32x2{1.f - lw, lw} * col_f32x2{as, as};
           const col_f32x2 g12 = t2 * col_f32x2{1.f - lh, 1.f - lh}, g34 = t2 * col_f32x2{lh, lh};
           const unsigned pidx = (unsigned)(__mul24(y0, wwid[l]) + x0 + woff[l]);
-          if (!(PCT_BCOL_KO & 1)) {
+          if (!(PCT_BCOL_KO & (1 | 64))) {
             lds_u32 *cp = (lds_u32 *)(pool + pidx * 4u);
             lds_u32 *cq = (lds_u32 *)(pool + (pidx + (unsigned)wwid[l]) * 4u);
             __hip_atomic_fetch_add(cp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -707,33 +738,33 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
     };
     // ---- flush of one window: (T, n) -> the two 32-bit sums -> two float atomics per (texel, channel pair) with n > 0 -------
     auto flush_window = [&](const int l) {
-      // a wave takes every NW-th window row; one wave instruction covers 8 pixels x 8 channel pairs (lanes on consecutive
-      // dwords of grad_value: 512 contiguous bytes); rows and columns outside the map (the apron) are skipped
+      // a wave takes every NW-th window row; one wave instruction covers 4 pixels x 16 channels: ONE atomic instruction whose
+      // lanes sit on consecutive dwords of grad_value (whole 64-byte head-pixels; two lanes share an accumulator pair and take
+      // its low / high field).  Rows and columns outside the map (the apron) and untouched texels (n = 0) are skipped.
       const int H = Hs[l], W = Ws[l];
       const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-      const int pair = lane & 7, dxl = lane >> 3;
-      float *glev = gimg + (long long)St[l] * MD + 2 * pair;
+      const int ch = lane & 15, dxl = lane >> 4;
+      float *glev = gimg + (long long)St[l] * MD + ch;
+      const unsigned plane_b = (unsigned)BCOL_CNT_BYTES + (unsigned)(ch >> 1) * (unsigned)BCOL_PLANE_BYTES;
       for (int r = wv; r < whgt[l]; r += NW) {
         const int y = wy0[l] + r;
         if ((unsigned)y >= (unsigned)H) continue;
         const int rowi = wbase[l] + r * wwid[l];
         float *grow = glev + (long long)y * W * MD;
-        for (int c0 = 0; c0 < wwid[l]; c0 += 8) {
+        for (int c0 = 0; c0 < wwid[l]; c0 += 4) {
           const int xw = c0 + dxl, x = wx0[l] + xw;
           if (xw < wwid[l] && (unsigned)x < (unsigned)W) {
             const unsigned n = *reinterpret_cast<const unsigned *>(pool + (size_t)(rowi + xw) * 4);
             if (n != 0u) {
-              const unsigned long long T = *reinterpret_cast<const unsigned long long *>(
-                  pool + BCOL_CNT_BYTES + (size_t)pair * BCOL_PLANE_BYTES + (size_t)(rowi + xw) * 8);
+              const unsigned long long T = *reinterpret_cast<const unsigned long long *>(pool + plane_b + (size_t)(rowi + xw) * 8);
               constexpr unsigned K = 0x4B400000u;
               const unsigned nK = n * K;
               const int lo = (int)((unsigned)T - nK);
               const unsigned long long U = (unsigned long long)n * K + (unsigned long long)(long long)lo;
               const int hi = (int)((unsigned)(T >> 32) - (unsigned)(U >> 32) - nK);
-              float *dst = grow + (long long)x * MD;
+              const int mine = (ch & 1) ? hi : lo;
               if (!(PCT_BCOL_KO & 4)) {
-                if (lo != 0) unsafeAtomicAdd(dst, (float)lo * inv_scale);
-                if (hi != 0) unsafeAtomicAdd(dst + 1, (float)hi * inv_scale);
+                if (mine != 0) unsafeAtomicAdd(grow + (long long)x * MD, (float)mine * inv_scale);
               }
             }
           }
@@ -757,7 +788,7 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
         int used = 0;
 #pragma unroll
         for (int l = 0; l < L; ++l) used += phase_of[l] == ph ? wsize[l] : 0;
-        {
+        if (!(PCT_BCOL_KO & 128)) {
           const col_f32x4 z = {0.f, 0.f, 0.f, 0.f};
           for (int i = tid; i * 4 < used; i += BLOCK) *reinterpret_cast<col_f32x4 *>(pool + (size_t)i * 16) = z;   // counts
 #pragma unroll
