@@ -46,6 +46,10 @@ namespace pct {
                                  16 = no dots pass, 32 = no scatter pass, 64 = no count adds, 128 = no zeroing */
 #endif
 
+#ifndef PCT_BCOL_PRIO
+#define PCT_BCOL_PRIO 0         /* wave priorities (s_setprio): 1 = dots 3 / scatter 2 / rest 0, 2 = dots 2 / scatter 3, 3 = flush raised too */
+#endif
+
 constexpr int BCOL_BLOCK = 256;
 constexpr int BCOL_GPX = 1092;                                  // pixels per pool (= 4 mod 32: the 8 planes of one pixel start 8 banks apart)
 constexpr int BCOL_CNT_BYTES = BCOL_GPX * 4;                    // contribution counts, one dword per pixel
@@ -806,9 +810,11 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
         __syncthreads();
       }
       if (fixed_ok) {
+        if (PCT_BCOL_PRIO) __builtin_amdgcn_s_setprio(PCT_BCOL_PRIO == 2 ? 2 : 3);
         [&]<int... Ls>(std::integer_sequence<int, Ls...>) {
           ([&] { if (!(PCT_BCOL_KO & 16) && phase_of[Ls] == ph) dots_lds(std::integral_constant<int, Ls>{}); }(), ...);
         }(std::make_integer_sequence<int, L>{});
+        if (PCT_BCOL_PRIO) __builtin_amdgcn_s_setprio(0);
         __syncthreads();                                                      // (B2) every wave is done with the values
         if (ph == nph - 1 && have_n) issue_loc(b_n, m_n, qv_n, raw);           // in flight until the next iteration
         int used = 0;
@@ -839,13 +845,16 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
           for (int u = 0; u < 8; ++u) gor[u] = (d & 4u) ? a[(u + 4) & 7] : a[u];
         }
         auto scatter_lds = [&](auto lc) { scatter_impl(lc, gor); };
+        if (PCT_BCOL_PRIO) __builtin_amdgcn_s_setprio(PCT_BCOL_PRIO == 2 ? 3 : 2);
         [&]<int... Ls>(std::integer_sequence<int, Ls...>) {
           ([&] { if (!(PCT_BCOL_KO & 32) && phase_of[Ls] == ph) scatter_lds(std::integral_constant<int, Ls>{}); }(), ...);
         }(std::make_integer_sequence<int, L>{});
+        if (PCT_BCOL_PRIO) __builtin_amdgcn_s_setprio(PCT_BCOL_PRIO == 3 ? 1 : 0);
         __syncthreads();                                                      // (B4) every add of this phase is in the pool
 #pragma unroll
         for (int l = 0; l < L; ++l)
           if (phase_of[l] == ph) flush_window(l);
+        if (PCT_BCOL_PRIO == 3) __builtin_amdgcn_s_setprio(0);
       }
     }
     if ((nph == 0 || !fixed_ok) && have_n) issue_loc(b_n, m_n, qv_n, raw);
