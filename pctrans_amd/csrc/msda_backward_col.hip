@@ -50,6 +50,10 @@ namespace pct {
 #define PCT_BCOL_PRIO 0         /* wave priorities (s_setprio): 1 = dots 3 / scatter 2 / rest 0, 2 = dots 2 / scatter 3, 3 = flush raised too */
 #endif
 
+#ifndef PCT_BCOL_STAMP
+#define PCT_BCOL_STAMP 0        /* diagnostic build: per-part cycle sums of wave 0 (s_memtime), tools/stamp_msda_bwd.py */
+#endif
+
 constexpr int BCOL_BLOCK = 256;
 constexpr int BCOL_GPX = 1092;                                  // pixels per pool (= 4 mod 32: the 8 planes of one pixel start 8 banks apart)
 constexpr int BCOL_CNT_BYTES = BCOL_GPX * 4;                    // contribution counts, one dword per pixel
@@ -73,8 +77,21 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn, const int N,
     const int S, const int M, float *__restrict__ grad_value, float *__restrict__ grad_loc,
-    float *__restrict__ grad_attn, unsigned *__restrict__ queue, unsigned char *__restrict__ flags, const int flag_cap)
+    float *__restrict__ grad_attn, unsigned *__restrict__ queue, unsigned char *__restrict__ flags, const int flag_cap,
+    unsigned long long *__restrict__ stamps)
 {
+  unsigned long long t_prev = 0, t_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int part) {
+    if constexpr (PCT_BCOL_STAMP && !DIRECT) {
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (part >= 0) t_sum[part] += t - t_prev;
+      t_prev = t;
+    }
+  };
+
   constexpr int P = 4, D = 16, PXB = 64, BLOCK = BCOL_BLOCK, NW = BLOCK / 64;
   static_assert(L >= 1 && L <= 5, "unsupported geometry");
   typedef unsigned col_u32x4 __attribute__((ext_vector_type(4)));
@@ -90,7 +107,8 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
   unsigned *next_idx = mx + NW * 2;                                            // the workgroup's next item
 
   int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = tid >> 6;
+  int lane = tid & 63;
   const int MD = M * D;
   if constexpr (DIRECT) {
     unsigned *aw_ = reinterpret_cast<unsigned *>(flags + BCOL_FLAG_BYTES);
@@ -491,6 +509,7 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
     issue_loc(b, m, qv, raw);
   }
 
+  stamp(-1);
   while (have) {
     asm volatile("" : "+v"(tid), "+v"(qi), "+v"(lane_slot), "+v"(lane_c0));
     unsigned rfetch = 0u;
@@ -524,7 +543,9 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
       }
       next_idx[0] = fetched;
     }
+    stamp(0);
     __syncthreads();                                                          // (A) boxes visible; pool free (previous flush read)
+    stamp(1);
     int item_n, b_n = 0, m_n = 0, qv_n = 0;
     {
       const unsigned nxt = __builtin_amdgcn_readfirstlane(next_idx[0]);
@@ -632,8 +653,10 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
         mx[wave * 2 + 1] = amax;
       }
     }
+    stamp(2);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                                                          // (B1) phase 0 staged; bounds visible
+    stamp(3);
     bool fixed_ok;
     float scale, inv_scale;
     {
@@ -768,33 +791,49 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
     };
     // ---- flush of one window: (T, n) -> the two 32-bit sums -> two float atomics per (texel, channel pair) with n > 0 -------
     auto flush_window = [&](const int l) {
+      // (opaque per call: the per-lane pointers and plane offsets below do not depend on the phase, and hoisted out of the
+      // phase loop -- four levels of them -- they were registers taken from the dots and scatter passes)
+      asm volatile("" : "+v"(lane));
       // a wave takes every NW-th window row; one wave instruction covers 4 pixels x 16 channels: ONE atomic instruction whose
       // lanes sit on consecutive dwords of grad_value (whole 64-byte head-pixels; two lanes share an accumulator pair and take
       // its low / high field).  Rows and columns outside the map (the apron) and untouched texels (n = 0) are skipped.
+      // Four column blocks at a time with all their LDS reads (counts and accumulators, unconditionally) in flight together:
+      // one block per round trip -- count, branch, accumulator, decode, atomic -- took 800 cycles per block, a third of an item.
       const int H = Hs[l], W = Ws[l];
       const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
       const int ch = lane & 15, dxl = lane >> 4;
       float *glev = gimg + (long long)St[l] * MD + ch;
       const unsigned plane_b = (unsigned)BCOL_CNT_BYTES + (unsigned)(ch >> 1) * (unsigned)BCOL_PLANE_BYTES;
+      constexpr int UF = 4;
       for (int r = wv; r < whgt[l]; r += NW) {
         const int y = wy0[l] + r;
         if ((unsigned)y >= (unsigned)H) continue;
         const int rowi = wbase[l] + r * wwid[l];
         float *grow = glev + (long long)y * W * MD;
-        for (int c0 = 0; c0 < wwid[l]; c0 += 4) {
-          const int xw = c0 + dxl, x = wx0[l] + xw;
-          if (xw < wwid[l] && (unsigned)x < (unsigned)W) {
-            const unsigned n = *reinterpret_cast<const unsigned *>(pool + (size_t)(rowi + xw) * 4);
-            if (n != 0u) {
-              const unsigned long long T = *reinterpret_cast<const unsigned long long *>(pool + plane_b + (size_t)(rowi + xw) * 8);
+        for (int c0 = 0; c0 < wwid[l]; c0 += 4 * UF) {
+          unsigned n[UF];
+          unsigned long long T[UF];
+          int xs[UF];
+#pragma unroll
+          for (int u = 0; u < UF; ++u) {
+            const int xw = c0 + 4 * u + dxl, x = wx0[l] + xw;
+            const bool okx = xw < wwid[l] && (unsigned)x < (unsigned)W;
+            xs[u] = okx ? x : -1;
+            const int idx = rowi + (okx ? xw : 0);                               // (a pixel of this row in any case)
+            n[u] = *reinterpret_cast<const unsigned *>(pool + (size_t)idx * 4);
+            T[u] = *reinterpret_cast<const unsigned long long *>(pool + plane_b + (size_t)idx * 8);
+          }
+#pragma unroll
+          for (int u = 0; u < UF; ++u) {
+            if (xs[u] >= 0 && n[u] != 0u) {
               constexpr unsigned K = 0x4B400000u;
-              const unsigned nK = n * K;
-              const int lo = (int)((unsigned)T - nK);
-              const unsigned long long U = (unsigned long long)n * K + (unsigned long long)(long long)lo;
-              const int hi = (int)((unsigned)(T >> 32) - (unsigned)(U >> 32) - nK);
+              const unsigned nK = n[u] * K;
+              const int lo = (int)((unsigned)T[u] - nK);
+              const unsigned long long U = (unsigned long long)n[u] * K + (unsigned long long)(long long)lo;
+              const int hi = (int)((unsigned)(T[u] >> 32) - (unsigned)(U >> 32) - nK);
               const int mine = (ch & 1) ? hi : lo;
               if (!(PCT_BCOL_KO & 4)) {
-                if (mine != 0) unsafeAtomicAdd(grow + (long long)x * MD, (float)mine * inv_scale);
+                if (mine != 0) unsafeAtomicAdd(grow + (long long)xs[u] * MD, (float)mine * inv_scale);
               }
             }
           }
@@ -808,6 +847,7 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
         stage_phase(ph);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        stamp(9);
       }
       if (fixed_ok) {
         if (PCT_BCOL_PRIO) __builtin_amdgcn_s_setprio(PCT_BCOL_PRIO == 2 ? 2 : 3);
@@ -815,6 +855,7 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
           ([&] { if (!(PCT_BCOL_KO & 16) && phase_of[Ls] == ph) dots_lds(std::integral_constant<int, Ls>{}); }(), ...);
         }(std::make_integer_sequence<int, L>{});
         if (PCT_BCOL_PRIO) __builtin_amdgcn_s_setprio(0);
+        stamp(4);
         __syncthreads();                                                      // (B2) every wave is done with the values
         if (ph == nph - 1 && have_n) issue_loc(b_n, m_n, qv_n, raw);           // in flight until the next iteration
         int used = 0;
@@ -846,15 +887,19 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
         }
         auto scatter_lds = [&](auto lc) { scatter_impl(lc, gor); };
         if (PCT_BCOL_PRIO) __builtin_amdgcn_s_setprio(PCT_BCOL_PRIO == 2 ? 3 : 2);
+        stamp(5);
         [&]<int... Ls>(std::integer_sequence<int, Ls...>) {
           ([&] { if (!(PCT_BCOL_KO & 32) && phase_of[Ls] == ph) scatter_lds(std::integral_constant<int, Ls>{}); }(), ...);
         }(std::make_integer_sequence<int, L>{});
         if (PCT_BCOL_PRIO) __builtin_amdgcn_s_setprio(PCT_BCOL_PRIO == 3 ? 1 : 0);
+        stamp(6);
         __syncthreads();                                                      // (B4) every add of this phase is in the pool
+        stamp(7);
 #pragma unroll
         for (int l = 0; l < L; ++l)
           if (phase_of[l] == ph) flush_window(l);
         if (PCT_BCOL_PRIO == 3) __builtin_amdgcn_s_setprio(0);
+        stamp(8);
       }
     }
     if ((nph == 0 || !fixed_ok) && have_n) issue_loc(b_n, m_n, qv_n, raw);
@@ -872,6 +917,11 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
     b = b_n;
     m = m_n;
     qv = qv_n;
+    stamp(10);
+  }
+  if constexpr (PCT_BCOL_STAMP && !DIRECT) {
+    if (tid == 0 && stamps)
+      for (int i = 0; i < 16; ++i) stamps[(size_t)blockIdx.x * 16 + i] = t_sum[i];
   }
 }
 
@@ -931,6 +981,8 @@ static unsigned char *bcol_flag_buffer(hipStream_t stream)
   return base[dev] + (size_t)(seq[dev]++ % RING) * BCOL_FLAG_STRIDE;
 }
 
+unsigned long long *win_stamp_buffer();                                      // msda_forward_win.hip (diagnostic)
+
 // returns -100 when this geometry is not covered (caller uses another kernel)
 int launch_msda_backward_col(const float *value, const int64_t *shapes, const int64_t *starts, const float *loc,
                              const float *attn, const float *grad_out, int N, int S, int M, int D, int L, int Lq,
@@ -967,9 +1019,9 @@ int launch_msda_backward_col(const float *value, const int64_t *shapes, const in
     if (attr_rc != hipSuccess) return (int)attr_rc;                                                                        \
     if (attr_rc2 != hipSuccess) return (int)attr_rc2;                                                                      \
     hipLaunchKernelGGL((msda_backward_col_kernel<L_, false>), grid, block, lds, stream, grad_out, value, shapes, starts,   \
-                       loc, attn, N, S, M, grad_value, grad_loc, grad_attn, queue, flags, flag_cap);                                 \
+                       loc, attn, N, S, M, grad_value, grad_loc, grad_attn, queue, flags, flag_cap, PCT_BCOL_STAMP ? win_stamp_buffer() : nullptr);                                 \
     hipLaunchKernelGGL((msda_backward_col_kernel<L_, true>), grid, block, lds_direct, stream, grad_out, value, shapes,     \
-                       starts, loc, attn, N, S, M, grad_value, grad_loc, grad_attn, nullptr, flags, flag_cap);                       \
+                       starts, loc, attn, N, S, M, grad_value, grad_loc, grad_attn, nullptr, flags, flag_cap, nullptr);                       \
   } while (0)
   if (L == 3) PCT_BCOL(3);
   else if (L == 4) PCT_BCOL(4);
