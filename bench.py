@@ -334,6 +334,19 @@ def main():
 
     for _ in range(2):          # untimed pre-warm: MIOpen's first-call kernel search for the 3x3 convolutions
         step()
+    # ... and until the step time has settled: as the first GPU process on a fresh box the first ~8 steps run 15-20 % slower
+    # than the steady state (measured: 137 ms per step with 5 untimed steps in front, 114.0 with 12, on the same boxes the
+    # second run of the same command gave 113.6).  Bounded: at most 12 more untimed steps; no collective inside.
+    prev = None
+    for _ in range(12):
+        torch.cuda.synchronize(device)
+        t_s = time.perf_counter()
+        step()
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t_s
+        if prev is not None and abs(dt - prev) <= 0.015 * prev and abs(dt - prev2) <= 0.03 * prev:
+            break
+        prev2, prev = (prev if prev is not None else dt), dt
     for _ in range(args.warmup):
         step()
 
