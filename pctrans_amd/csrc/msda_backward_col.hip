@@ -19,7 +19,7 @@
 //     instruction against 2 x 4.3 for ds_add_u32, and no per-value integer subtraction).  A 17th plane counts the
 //     contributions n per texel; the flush recovers both 32-bit sums exactly from (T, n): low = T_lo - n K, carry =
 //     (n K + low) >> 32, high = T_hi - carry - n K (K = 0x4B400000).  Integer sums: deterministic, order-independent;
-//     scale = one power of two per item from max|grad_out| max|attn|, 2^-20 of that bound per contribution, 1024
+//     scale = one power of two per item from max|grad_out| max|attn|, 2^-21 of that bound per contribution, 1024
 //     contributions cannot overflow; non-finite bounds send the item down the direct float path;
 //   * one coalesced flush per window: two global float atomics per (texel, channel pair) with n > 0, lanes on
 //     consecutive dwords;
@@ -673,8 +673,9 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
       (void)frexpf(C, &e);                                                    // C < 2^e
       fixed_ok = gb < 0x7f800000u && ab < 0x7f800000u && C < 1e30f;
       // a window dword receives at most BLOCK * P = 1024 contributions w_corner * attn * grad_out, each below C < 2^e:
-      // rounded to multiples of 2^(e - 20), the int32 sums stay below 2^30
-      const int shift = max(min(20 - e, 100), -100);
+      // rounded to multiples of 2^(e - 21) every contribution is below 2^21 in magnitude and the int32 sums stay inside
+      // (-2^31, 2^31) (a contribution also has to stay below 2^22 for the magic-constant rounding)
+      const int shift = max(min(21 - e, 100), -100);
       scale = uni(ldexpf(1.f, shift));
       inv_scale = uni(ldexpf(1.f, -shift));
     }
