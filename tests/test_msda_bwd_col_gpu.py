@@ -220,3 +220,35 @@ def test_backward_column_flag_overflow_route_matches():
     env = dict(os.environ, PCT_BCOL_FLAG_CAP="16")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_backward_column_replays_from_a_hip_graph(MSDA, lib):
+    """Captured in a HIP graph, the two launches of the column backward (main + DIRECT) replay any number of times: the work
+    queue's counters, the flag bytes and the `any` / `readers` words all reset themselves, and a captured launch owns its flag
+    buffer.  Uniform-random locations at the coarse levels + model-like ones elsewhere exercise both launches."""
+    c = make_case(seed=79, N=2, M=8, D=16, Lq=n_px(P2), P=4, shapes=P2, model_like=True, px_sigma=6.0)
+    go = grad_out_for(c, 179)
+    args = [dev(c["value"]), dev(c["shapes"]), dev(c["starts"]), dev(c["loc"]), dev(c["attn"]), dev(go), 64]
+    with force(lib, B_COL):
+        eager = MSDA.ms_deform_attn_backward(*args)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            MSDA.ms_deform_attn_backward(*args)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = MSDA.ms_deform_attn_backward(*args)
+            assert lib.pct_msda_last_bwd_kernel() == B_COL
+        for _ in range(3):
+            for t in out:
+                t.fill_(float("nan"))
+            g.replay()
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(out[1].cpu().numpy(), eager[1].cpu().numpy())       # grad_loc: bitwise
+            np.testing.assert_array_equal(out[2].cpu().numpy(), eager[2].cpu().numpy())       # grad_attn: bitwise
+            scale = float(eager[0].abs().max())
+            assert float((out[0] - eager[0]).abs().max()) <= 1e-5 * scale                     # grad_value: float atomics
+        again = MSDA.ms_deform_attn_backward(*args)                                           # eager launches in between
+        np.testing.assert_array_equal(again[1].cpu().numpy(), eager[1].cpu().numpy())
