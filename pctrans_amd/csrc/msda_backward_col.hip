@@ -115,6 +115,8 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
     unsigned any = 0u;
     if (tid == 0) {
       any = __hip_atomic_load(aw_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (the value must be HERE before this workgroup counts itself in: the last one to count clears the word)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(any)::"memory");
       const unsigned r = atomicAdd(aw_ + 1, 1u);
       if (r + 1u == gridDim.x) {
         __hip_atomic_store(aw_, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
