@@ -41,6 +41,9 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float *__restrict__ cost
   const float *C = cost + (size_t)b * Q * ldg;
   int *out = row_for_target + (size_t)b * ldg;
   for (int j = lane; j < ldg; j += 64) out[j] = -1;
+  // (the kernel clears its own status word: a hipMemsetAsync recorded into a HIP graph does not replay reliably on ROCm
+  // 7.2, msda_backward.hip; one lane, one wave per problem -- the later `status[b] = 1` of the same lane is ordered behind it)
+  if (lane == 0) status[b] = 0;
   if (g <= 0) return;
   if (g > ldg || g > Q || g > LSAP_MAXG) {        // more targets than columns / queries: no assignment exists
     if (lane == 0) status[b] = 1;
@@ -154,8 +157,6 @@ int launch_lsap(const float *cost, int batch, int num_query, int ld_target, cons
 {
   if (batch == 0) return 0;
   if (num_query > LSAP_MAXQ || ld_target > LSAP_MAXG) return -4;
-  hipError_t e = hipMemsetAsync(status, 0, sizeof(int) * (size_t)batch, stream);
-  if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(lsap_kernel, dim3((unsigned)batch), dim3(64), 0, stream, cost, num_query, ld_target, num_target,
                      row_for_target, status);
   return (int)hipGetLastError();
