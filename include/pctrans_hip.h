@@ -95,7 +95,7 @@ PCT_API int pct_ms_deform_attn_fused_forward_f32(const float *value, const int64
 /* ---- MSDeformAttn backward: replaces ms_deform_attn_cuda_backward (cu:88-158) ----------------------------- */
 /* grad_value [as value], grad_sampling_loc [as sampling_loc], grad_attn_weight [as attn_weight]; all three are
  * fully defined on return (grad_value is zero-filled on `stream` by a kernel of the library before the scatter-add -- not
- * by hipMemsetAsync, whose node does not replay reliably from a HIP graph on ROCm 7.2).  A call is two or three launches on
+ * by hipMemsetAsync, whose node did not replay reliably from a torch.cuda.graph capture on ROCm 7.2).  A call is two or three launches on
  * `stream` (zero-fill, the kernel, and for the pyramid-column kernel a second launch for levels whose windows do not fit,
  * which ends at once when there are none); it may be recorded into a HIP graph and replayed.  The pyramid-column kernel keeps
  * one 64 MB block of per-item flag buffers per device for the life of the process (allocated at the first call outside stream

@@ -177,8 +177,8 @@ int launch_msda_backward_col(const float *value, const int64_t *shapes, const in
 int msda_bwd_kernel_choice();
 void note_msda_bwd_kernel(int k);
 
-// Zero-fill by a kernel of our own instead of hipMemsetAsync.  A memset recorded into a HIP graph does not replay
-// reliably on ROCm 7.2: from the second replay on, the node wrote a garbage dword into every fourth / second element of
+// Zero-fill by a kernel of our own instead of hipMemsetAsync.  A memset recorded into a HIP graph by torch.cuda.graph does
+// not replay reliably on ROCm 7.2 (a stand-alone capture of the same memsets does: tools/micro/graph_memset_replay.hip): from the second replay on, the node wrote a garbage dword into every fourth / second element of
 // grad_value (tools/diag_bwd_graph2.py: the windowed and the column backward both came out 0.26 x max|grad_value| off in
 // exactly those channels, the first replay and every eager launch being right) -- the same defect the work-queue counters
 // ran into in round 1.  Any 4-byte aligned range; 16-byte stores over the aligned middle.

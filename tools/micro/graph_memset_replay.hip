@@ -1,0 +1,53 @@
+// Reproducer (development tool, not part of the library): does a hipMemsetAsync recorded into a HIP graph replay?
+//   hipcc -O2 --offload-arch=gfx950 graph_memset_replay.hip -o graph_memset_replay && ./graph_memset_replay
+// Graph = { memset(buf, 0, bytes); add_one(buf) }; before every replay the buffer is filled with 7.0 by a plain kernel.
+// Expected after every replay: 1.0 everywhere.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+__global__ void fill(float *p, size_t n, float v)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void add_one(float *p, size_t n)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] += 1.0f;
+}
+
+int main()
+{
+  const size_t sizes[] = {1u << 16, 5570560, 89128960};            // floats: 256 KB, 22 MB (grad_value at batch 2), 356 MB (batch 32)
+  for (size_t n : sizes) {
+    float *d;
+    hipMalloc(&d, n * 4);
+    float *h = (float *)malloc(n * 4);
+    hipStream_t s;
+    hipStreamCreate(&s);
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    hipStreamBeginCapture(s, hipStreamCaptureModeGlobal);
+    hipMemsetAsync(d, 0, n * 4, s);
+    hipLaunchKernelGGL(add_one, dim3(1024), dim3(256), 0, s, d, n);
+    hipStreamEndCapture(s, &g);
+    hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    for (int r = 0; r < 4; ++r) {
+      hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, s, d, n, 7.0f);
+      hipGraphLaunch(ge, s);
+      hipStreamSynchronize(s);
+      hipMemcpy(h, d, n * 4, hipMemcpyDeviceToHost);
+      size_t bad = 0, first = 0;
+      for (size_t i = 0; i < n; ++i)
+        if (h[i] != 1.0f) { if (!bad) first = i; ++bad; }
+      printf("n = %9zu floats, replay %d: %zu wrong", n, r, bad);
+      if (bad) printf(" (first at %zu: %g, next %g %g %g)", first, h[first], h[first + 1], h[first + 2], h[first + 3]);
+      printf("\n");
+    }
+    hipGraphExecDestroy(ge);
+    hipGraphDestroy(g);
+    hipStreamDestroy(s);
+    hipFree(d);
+    free(h);
+  }
+  return 0;
+}
