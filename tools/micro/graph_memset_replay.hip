@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 __global__ void fill(float *p, size_t n, float v)
 {
@@ -31,6 +32,18 @@ int main()
     hipLaunchKernelGGL(add_one, dim3(1024), dim3(256), 0, s, d, n);
     hipStreamEndCapture(s, &g);
     hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (getenv("DESTROY_GRAPH_FIRST")) {          // torch.cuda.CUDAGraph keeps only the executable graph
+      hipGraphDestroy(g);
+      g = nullptr;
+    }
+    if (getenv("CHURN_HOST_HEAP")) {              // overwrite whatever host memory the capture may have freed
+      for (int it = 0; it < 4000; ++it) {
+        const size_t sz = 16 + (size_t)(rand() % (1 << 20));
+        unsigned char *q = (unsigned char *)malloc(sz);
+        memset(q, 0xAB, sz);
+        free(q);
+      }
+    }
     for (int r = 0; r < 4; ++r) {
       hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, s, d, n, 7.0f);
       hipGraphLaunch(ge, s);
@@ -44,7 +57,7 @@ int main()
       printf("\n");
     }
     hipGraphExecDestroy(ge);
-    hipGraphDestroy(g);
+    if (g) hipGraphDestroy(g);
     hipStreamDestroy(s);
     hipFree(d);
     free(h);
