@@ -21,8 +21,10 @@
 //     (n K + low) >> 32, high = T_hi - carry - n K (K = 0x4B400000).  Integer sums: deterministic, order-independent;
 //     scale = one power of two per item from max|grad_out| max|attn|, 2^-21 of that bound per contribution, 1024
 //     contributions cannot overflow; non-finite bounds send the item down the direct float path;
-//   * one coalesced flush per window: two global float atomics per (texel, channel pair) with n > 0, lanes on
-//     consecutive dwords;
+//   * same-address LDS atomics are served a lane per clock (8 x 8 queries of the finest level share one texel of the
+//     coarsest): step t of lane i adds channel pair (t + i) % 8 and the lane rows take a level's points in rotated order;
+//   * one coalesced flush per window: one float atomic per (texel, channel) with n > 0 and a non-zero sum, a wave
+//     instruction covering 4 pixels x 16 channels (consecutive dwords), four such blocks' LDS reads in flight together;
 //   * the two passes share one pool (values, then accumulators), so a workgroup holds 1092 window pixels in 74 KB: the four
 //     windows of a column with model-like offsets (~1 300 px) take two phases, the reference's init-like ones a single one;
 //   * levels whose box exceeds the pool (and items whose bounds are not finite) are only FLAGGED here -- one byte per item --
