@@ -15,36 +15,12 @@
 //
 // Under autocast the reference's convolutions take bf16 inputs/weights with fp32 accumulation and emit bf16; here the
 // hidden activations are likewise rounded to bf16 between layers 0 and 1 and the logits are stored as bf16.
-#include "msda_common.hpp"
+#include "dmh_common.hpp"
 
 namespace pct {
 
-typedef __bf16 dm_bf16x4 __attribute__((ext_vector_type(4)));
-typedef short dm_s16x4 __attribute__((ext_vector_type(4)));
-typedef float dm_f32x4 __attribute__((ext_vector_type(4)));
-
 constexpr int DMM_PT = 8;        // pixel tiles (16 px each) per wave
 constexpr int DMM_BLOCK = 256;
-
-typedef float dm_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 dm_bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned dm_u32x2 __attribute__((ext_vector_type(2)));
-
-// two v_cvt_pk_bf16_f32 (round to nearest even), no per-element conversions and byte permutes
-__device__ __forceinline__ dm_s16x4 pack_bf16x4(float a, float b, float c, float d)
-{
-  const dm_u32x2 v = {__builtin_bit_cast(unsigned, __builtin_convertvector(dm_f32x2{a, b}, dm_bf16x2)),
-                      __builtin_bit_cast(unsigned, __builtin_convertvector(dm_f32x2{c, d}, dm_bf16x2))};
-  return __builtin_bit_cast(dm_s16x4, v);
-}
-
-// relu as ONE v_max_f32: fmaxf on an MFMA result makes hipcc emit a canonicalising v_max_f32 x, x, x first
-__device__ __forceinline__ float dm_relu(float x)
-{
-  float y;
-  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-  return y;
-}
 
 // feat [N, 16, H, W] fp32, ref [N, Q, 2], params [N, Q, G] fp32 (G = 233 with rel coords, 217 without),
 // logits [N, Q, H*W] bf16
@@ -56,10 +32,7 @@ __global__ __launch_bounds__(DMM_BLOCK) void dmh_logits_mfma_kernel(const float 
                                                                     const int blocks_per_image,
                                                                     __bf16 *__restrict__ logits)
 {
-  constexpr int C = 16, HID = 8, CIN = REL ? C + 2 : C;
-  constexpr int G = CIN * HID + HID * HID + HID + HID + HID + 1;
-  constexpr int OFF_W1 = CIN * HID, OFF_W2 = OFF_W1 + HID * HID, OFF_B0 = OFF_W2 + HID;
-  constexpr int OFF_B1 = OFF_B0 + HID, OFF_B2 = OFF_B1 + HID;
+  constexpr int C = DMH_C;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, g = lane >> 4;                    // MFMA column (pixel / weight row) and lane group
   const int HW = H * W;
@@ -67,91 +40,25 @@ __global__ __launch_bounds__(DMM_BLOCK) void dmh_logits_mfma_kernel(const float 
   const int pb = blockIdx.x - n * blocks_per_image;
   const int px_base = (pb * (DMM_BLOCK / 64) + wave) * (DMM_PT * 16);
 
-  // ---- B operand of layer 0: feat[ch = 4g + j][px] for my pixel column of each tile (kept for all query pairs) ----
-  // The relative-coordinate inputs  wx * (ref_x - loc_x) + wy * (ref_y - loc_y)  split into a per-query constant
-  // (folded into the bias, 8 FMAs per query pair instead of per pixel tile) and a per-pixel part that goes through the
-  // matrix core EXACTLY: a pixel coordinate (an integer below 2^16) is the sum of two bf16 pieces, a weight the sum of
-  // three, and the six products per axis fill 12 of the 16 k-slots of one more MFMA (k = 2 i + j: weight piece i times
-  // coordinate piece j; exact products, fp32 accumulation).  Was: 2 subtractions + 8 FMAs per lane and tile.
+  // ---- B operands of layer 0 for my pixel column of each tile (kept for all query pairs; dmh_common.hpp) -------------
   dm_s16x4 fb[DMM_PT], cb[DMM_PT];
   const float *fimg = feat + (size_t)n * C * HW;
-  const float half = (float)(stride / 2);
 #pragma unroll
   for (int t = 0; t < DMM_PT; ++t) {
     const int px = min(px_base + col * DMM_PT + t, HW - 1);        // lane `col` owns DMM_PT CONSECUTIVE pixels (one 16-B store)
-    const float *fp = fimg + (size_t)(4 * g) * HW + px;
-    fb[t] = pack_bf16x4(fp[0], fp[(size_t)HW], fp[(size_t)2 * HW], fp[(size_t)3 * HW]);
-    if constexpr (REL) {
-      const int y = px / W, x = px - y * W;
-      const float lxf = (float)(x * stride) + half, lyf = (float)(y * stride) + half;
-      const float xh = (float)(__bf16)lxf, yh = (float)(__bf16)lyf;
-      const float xl = lxf - xh, yl = lyf - yh;                  // exact, and exactly representable (integers < 2^16)
-      cb[t] = g == 0 ? pack_bf16x4(xh, xl, xh, xl) : g == 1 ? pack_bf16x4(xh, xl, yh, yl)
-            : g == 2 ? pack_bf16x4(yh, yl, yh, yl) : dm_s16x4{0, 0, 0, 0};
-    }
+    dmh_pixel_operands<REL>(fimg, HW, W, px, g, stride, fb[t], cb[t]);
   }
 
   const int npairs = (Q + 1) / 2;
   for (int pr = 0; pr < npairs; ++pr) {
-    // the query this lane's accumulator rows (4g .. 4g+3) belong to, and the query of my A-operand row `col`
-    const int q_acc = min(2 * pr + (g >> 1), Q - 1);
-    const int q_row = min(2 * pr + (col >> 3), Q - 1);
-    const float *pa = params + ((size_t)n * Q + q_acc) * G;      // for accumulator-side constants
-    const float *prw = params + ((size_t)n * Q + q_row) * G;     // for A-operand rows
-    const int hr = col & 7;                                      // hidden row of A-operand row `col`
-    const int r0 = (4 * g) & 7;                                  // first hidden row of my accumulator rows
-
-    // A operand, layer 0: W0feat[q_row][hr][ch = 4g + j]
-    const float *w0r = prw + hr * CIN + (REL ? 2 : 0) + 4 * g;
-    const dm_s16x4 a0 = pack_bf16x4(w0r[0], w0r[1], w0r[2], w0r[3]);
-    // A operand, layer 1: block-diagonal W1: row `col` (query col>>3, hidden hr) x k = 4g + j (query g>>1, hidden (4g+j)&7)
-    dm_s16x4 a1 = {0, 0, 0, 0};
-    if ((col >> 3) == (g >> 1)) {
-      const float *w1r = prw + OFF_W1 + hr * HID + ((4 * g) & 7);
-      a1 = pack_bf16x4(w1r[0], w1r[1], w1r[2], w1r[3]);
-    }
-    // accumulator-side constants of rows 4g .. 4g+3 (all of query q_acc)
-    float b0v[4], b1v[4], w2v[4], wxv[4], wyv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      b0v[r] = pa[OFF_B0 + r0 + r];
-      b1v[r] = pa[OFF_B1 + r0 + r];
-      w2v[r] = pa[OFF_W2 + r0 + r];
-      wxv[r] = REL ? pa[(r0 + r) * CIN + 0] : 0.f;
-      wyv[r] = REL ? pa[(r0 + r) * CIN + 1] : 0.f;
-    }
-    const float b2 = pa[OFF_B2];
-    dm_s16x4 ac = {0, 0, 0, 0};                                   // A operand of the coordinate MFMA: -(weight pieces)
-    if constexpr (REL) {
-      const float rx = ref[((size_t)n * Q + q_acc) * 2] * (float)(W * stride);
-      const float ry = ref[((size_t)n * Q + q_acc) * 2 + 1] * (float)(H * stride);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) b0v[r] = fmaf(wyv[r], ry, fmaf(wxv[r], rx, b0v[r]));
-      const float wxr = prw[hr * CIN + 0], wyr = prw[hr * CIN + 1];
-      const float x1 = (float)(__bf16)wxr, x2 = (float)(__bf16)(wxr - x1), x3 = (float)(__bf16)((wxr - x1) - x2);
-      const float y1 = (float)(__bf16)wyr, y2 = (float)(__bf16)(wyr - y1), y3 = (float)(__bf16)((wyr - y1) - y2);
-      ac = g == 0 ? pack_bf16x4(-x1, -x1, -x2, -x2) : g == 1 ? pack_bf16x4(-x3, -x3, -y1, -y1)
-         : g == 2 ? pack_bf16x4(-y2, -y2, -y3, -y3) : dm_s16x4{0, 0, 0, 0};
-    }
-    __bf16 *lrow = logits + ((size_t)n * Q + q_acc) * HW;
+    DmhPair<REL> pw;
+    pw.load(params, ref, n, Q, pr, col, g, H, W, stride);
+    __bf16 *lrow = logits + ((size_t)n * Q + pw.q_acc) * HW;
     const bool writer = (g & 1) == 0 && 2 * pr + (g >> 1) < Q;   // groups 0 / 2 hold the reduced logit of q0 / q1
 
     float outv[DMM_PT];
-#pragma unroll
-    for (int t = 0; t < DMM_PT; ++t) {
-      dm_f32x4 c0 = {b0v[0], b0v[1], b0v[2], b0v[3]};
-      if constexpr (REL) c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ac, cb[t], c0, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, fb[t], c0, 0, 0, 0);
-      // relu + bf16: accumulator rows 4g..4g+3 of pixel `col` == B operand k-slots 4g..4g+3 of column `col`
-      const dm_s16x4 xb = pack_bf16x4(dm_relu(c0[0]), dm_relu(c0[1]), dm_relu(c0[2]), dm_relu(c0[3]));
-      dm_f32x4 c1 = {b1v[0], b1v[1], b1v[2], b1v[3]};
-      c1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, xb, c1, 0, 0, 0);
-      float part = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) part = fmaf(w2v[r], dm_relu(c1[r]), part);
-      part += __shfl_xor(part, 16);                              // rows 4g..4g+3 (+) rows of the partner group
-      outv[t] = part + b2;
-    }
+    pw.template tiles<4>(fb, cb, outv);
+    pw.template tiles<4>(fb + 4, cb + 4, outv + 4);
     if (writer) {                                                // the lane's 8 consecutive pixels: one 16-byte store
       const int px0 = px_base + col * DMM_PT;
       if (px0 + DMM_PT <= HW && ((HW & 7) == 0)) {
@@ -167,17 +74,6 @@ __global__ __launch_bounds__(DMM_BLOCK) void dmh_logits_mfma_kernel(const float 
       }
     }
   }
-}
-
-// PyTorch upsample_bilinear2d source index (align_corners = False)
-__device__ __forceinline__ void dm_bilinear_src(int dst, float scale, int in_size, int &i0, int &i1, float &lam)
-{
-  float src = scale * ((float)dst + 0.5f) - 0.5f;
-  src = src < 0.f ? 0.f : src;
-  i0 = (int)src;
-  if (i0 > in_size - 1) i0 = in_size - 1;
-  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
-  lam = src - (float)i0;
 }
 
 // logits [N*Q, H, W] bf16 -> up [N*Q, 2H, 2W] bf16, amask [N*Q, th*tw] bytes
@@ -253,13 +149,11 @@ __global__ __launch_bounds__(256) void dmh_resize_kernel(const __bf16 *__restric
           const float a1l = left ? a1[k + 1] : a1[k], a1r = left ? a1[k + 2] : a1[k + 1];
           const float c_l = left ? c[k + 1] : c[k], c_r = left ? c[k + 2] : c[k + 1];
           const float p_l = left ? p[k + 1] : p[k], p_r = left ? p[k + 2] : p[k + 1];
-          oa[2 * k] = (__bf16)(hA0 * (wl0 * a0l + wl1 * a0r) + hA1 * (wl0 * a1l + wl1 * a1r));
-          ob[2 * k] = (__bf16)(0.75f * (wl0 * c_l + wl1 * c_r) + 0.25f * (wl0 * p_l + wl1 * p_r));
+          oa[2 * k] = (__bf16)dm_blend(hA0, hA1, wl0, wl1, a0l, a0r, a1l, a1r);
+          ob[2 * k] = (__bf16)dm_blend(0.75f, 0.25f, wl0, wl1, c_l, c_r, p_l, p_r);
           // odd output column 2xx+1: source cols (xx, xx+1) = entries (k+1, k+2), weights (3/4, 1/4)
-          oa[2 * k + 1] = (__bf16)(hA0 * (0.75f * a0[k + 1] + 0.25f * a0[k + 2]) +
-                                   hA1 * (0.75f * a1[k + 1] + 0.25f * a1[k + 2]));
-          ob[2 * k + 1] = (__bf16)(0.75f * (0.75f * c[k + 1] + 0.25f * c[k + 2]) +
-                                   0.25f * (0.75f * p[k + 1] + 0.25f * p[k + 2]));
+          oa[2 * k + 1] = (__bf16)dm_blend(hA0, hA1, 0.75f, 0.25f, a0[k + 1], a0[k + 2], a1[k + 1], a1[k + 2]);
+          ob[2 * k + 1] = (__bf16)dm_blend(0.75f, 0.25f, 0.75f, 0.25f, c[k + 1], c[k + 2], p[k + 1], p[k + 2]);
         }
         *reinterpret_cast<bf16x8_t *>(uplane + (size_t)(2 * y) * OW + 2 * x0) = oa;
         *reinterpret_cast<bf16x8_t *>(uplane + (size_t)(2 * y + 1) * OW + 2 * x0) = ob;
@@ -273,8 +167,7 @@ __global__ __launch_bounds__(256) void dmh_resize_kernel(const __bf16 *__restric
         dm_bilinear_src(oy, 0.5f, H, y0, y1, ly);
         dm_bilinear_src(ox, 0.5f, W, x0, x1, lxx);
         const float *ra = tile + (y0 - lo) * W, *rb = tile + (y1 - lo) * W;
-        uplane[(size_t)oy * OW + ox] =
-            (__bf16)((1.f - ly) * ((1.f - lxx) * ra[x0] + lxx * ra[x1]) + ly * ((1.f - lxx) * rb[x0] + lxx * rb[x1]));
+        uplane[(size_t)oy * OW + ox] = (__bf16)dm_blend(1.f - ly, ly, 1.f - lxx, lxx, ra[x0], ra[x1], rb[x0], rb[x1]);
       }
     }
   }
@@ -292,10 +185,7 @@ __global__ __launch_bounds__(256) void dmh_resize_kernel(const __bf16 *__restric
       if (y0 < r0 || y0 >= r1) continue;
       dm_bilinear_src(tx, sw, W, x0, x1, lxx);
       const float *ra = tile + (y0 - lo) * W, *rb = tile + (y1 - lo) * W;
-      float v = (1.f - ly) * ((1.f - lxx) * ra[x0] + lxx * ra[x1]) + ly * ((1.f - lxx) * rb[x0] + lxx * rb[x1]);
-      v = (float)(__bf16)v;                                          // torch's bf16 interpolate output
-      const float s = (float)(__bf16)(1.f / (1.f + expf(-v)));       // ... and bf16 sigmoid
-      mplane[i] = s < 0.5f ? 1 : 0;
+      mplane[i] = dm_mask_byte(ly, lxx, ra[x0], ra[x1], rb[x0], rb[x1]);
     }
   }
 }

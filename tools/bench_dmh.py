@@ -31,9 +31,8 @@ def timeit(fn, iters=10):
 
 
 for tgt in ((16, 16), (32, 32), (64, 64)):
-    for kern in ("mfma", "valu"):
-        os.environ["PCT_DMH_KERNEL"] = kern
-        t = timeit(lambda: dmh.dynamic_mask_head_forward(mf, ref, prm, 4, True, tgt, out_dtype=torch.bfloat16))
+    for kern in ("fused", "mfma", "fused", "mfma", "valu"):
+        t = timeit(lambda: dmh.dynamic_mask_head_forward(mf, ref, prm, 4, True, tgt, out_dtype=torch.bfloat16, kernel=kern))
         print("N=%d target=%s kernel=%s  %.3f ms" % (N, tgt, kern, t))
 t = timeit(lambda: dmh.dynamic_mask_head_forward(mf, ref, prm, 4, True, (32, 32), out_dtype=torch.float32))
 print("N=%d fp32 fused kernel %.3f ms" % (N, t))
