@@ -140,16 +140,19 @@ PCT_API int pct_dynamic_mask_head_forward_mfma(const float *mask_feat, const flo
                                                int stride, int rel_coord, int target_h, int target_w, void *scratch,
                                                void *up_logits, unsigned char *attn_mask, void *stream);
 
-/* ---- dynamic mask head, bf16-autocast configuration, ONE launch ------------------------------------------------
- * Same contract and bit-identical outputs (for finite logits) as pct_dynamic_mask_head_forward_mfma, without its
- * workspace: MLP, bf16 rounding, x2 upsample and attention mask in one kernel, so the [batch, num_query, height, width]
- * logits plane is never written to memory (csrc/dyn_mask_head_fused.hip).  Geometry: channels == 16, width == 128,
- * height % 8 == 0, (target_h, target_w) = (height, width) / s with s in {2, 4, 8}; anything else returns
- * PCT_ERR_UNSUPPORTED and the caller uses pct_dynamic_mask_head_forward_mfma. */
+/* ---- dynamic mask head, bf16-autocast configuration, one pass over the pixels ------------------------------------
+ * Same contract and bit-identical outputs (for finite logits) as pct_dynamic_mask_head_forward_mfma, without its logits
+ * plane: MLP, bf16 rounding, x2 upsample and attention mask in one kernel, so the [batch, num_query, height, width]
+ * logits are never written to memory (csrc/dyn_mask_head_fused.hip; a small launch in front of it re-packs the generated
+ * parameters).  `workspace`: caller-owned, batch * ceil(num_query / 2) * 5120 bytes, 16-byte aligned (the re-packed
+ * parameters; nothing is allocated inside the call).  Geometry: channels == 16, width == 128, height % 8 == 0,
+ * (target_h, target_w) = (height, width) / s with s in {2, 4, 8}; anything else returns PCT_ERR_UNSUPPORTED and the
+ * caller uses pct_dynamic_mask_head_forward_mfma. */
 PCT_API int pct_dynamic_mask_head_forward_fused_bf16(const float *mask_feat, const float *ref_points, const float *params,
                                                      int batch, int channels, int num_query, int height, int width,
                                                      int stride, int rel_coord, int target_h, int target_w,
-                                                     void *up_logits, unsigned char *attn_mask, void *stream);
+                                                     void *workspace, void *up_logits, unsigned char *attn_mask,
+                                                     void *stream);
 
 /* ---- fused residual add + LayerNorm:  out = LayerNorm(x + y) * gamma + beta  over the last dimension ----------
  * Replaces the `x + dropout(y)` / `nn.LayerNorm` pairs of the encoder and decoder layers in eval mode

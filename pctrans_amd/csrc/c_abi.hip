@@ -33,7 +33,7 @@ int launch_msda_backward(const void *, const int64_t *, const int64_t *, const v
                          int, int, int, int, int, int, int, void *, void *, void *, hipStream_t);
 void set_win_stamp_buffer(void *);
 int launch_dyn_mask_head_fused(const float *, const float *, const float *, int, int, int, int, int, int, int, int, int,
-                               void *, unsigned char *, hipStream_t);
+                               void *, void *, unsigned char *, hipStream_t);
 int launch_dyn_mask_head_mfma(const float *, const float *, const float *, int, int, int, int, int, int, int, int, int,
                               void *, void *, unsigned char *, hipStream_t);
 int launch_masked_attention(const void *, const void *, const void *, const unsigned char *, int, int, int, int, int,
@@ -269,19 +269,19 @@ int pct_dynamic_mask_head_forward_mfma(const float *mask_feat, const float *ref_
 
 int pct_dynamic_mask_head_forward_fused_bf16(const float *mask_feat, const float *ref_points, const float *params, int batch,
                                              int channels, int num_query, int height, int width, int stride,
-                                             int rel_coord, int target_h, int target_w, void *up_logits,
-                                             unsigned char *attn_mask, void *stream)
+                                             int rel_coord, int target_h, int target_w, void *workspace,
+                                             void *up_logits, unsigned char *attn_mask, void *stream)
 {
   if (batch < 0 || num_query < 0 || channels <= 0 || height <= 0 || width <= 0 || stride <= 0 || target_h <= 0 ||
       target_w <= 0)
     return PCT_ERR_BAD_ARG;
   if (batch == 0 || num_query == 0) return PCT_OK;
-  if (!mask_feat || !params || !up_logits || !attn_mask || (rel_coord && !ref_points)) return PCT_ERR_BAD_ARG;
+  if (!mask_feat || !params || !up_logits || !attn_mask || !workspace || (rel_coord && !ref_points)) return PCT_ERR_BAD_ARG;
   if (((uintptr_t)mask_feat | (uintptr_t)params | (uintptr_t)ref_points) & 3u) return PCT_ERR_ALIGNMENT;
-  if ((uintptr_t)up_logits & 15u) return PCT_ERR_ALIGNMENT;
+  if (((uintptr_t)up_logits | (uintptr_t)workspace) & 15u) return PCT_ERR_ALIGNMENT;
   if ((long long)height * width >= 0x7fffffffLL / 64) return PCT_ERR_UNSUPPORTED;
   const int r = pct::launch_dyn_mask_head_fused(mask_feat, ref_points, params, batch, channels, num_query, height, width,
-                                                stride, rel_coord, target_h, target_w, up_logits, attn_mask,
+                                                stride, rel_coord, target_h, target_w, workspace, up_logits, attn_mask,
                                                 static_cast<hipStream_t>(stream));
   return r == -100 ? PCT_ERR_UNSUPPORTED : r;
 }

@@ -29,10 +29,24 @@ constexpr int FZ_BAND = 8;             // rows per workgroup
 constexpr int FZ_TILES = 20;           // per wave: 2 x 8 own tiles + 4 halo tiles
 constexpr int FZ_SLOTS = FZ_BAND + 2;  // LDS rows per buffer: halo above, the band, halo below
 
+// one wave per (image, query pair): the pair's generated parameters in the form DmhPair::take reads them
+template <bool REL>
+__global__ __launch_bounds__(64) void dmh_prepare_kernel(const float *__restrict__ params, const float *__restrict__ ref,
+                                                         const int Q, const int H, const int W, const int stride,
+                                                         unsigned *__restrict__ ws)
+{
+  const int lane = threadIdx.x, col = lane & 15, g = lane >> 4;
+  const int npairs = (Q + 1) / 2;
+  const int n = blockIdx.x / npairs, pr = blockIdx.x - n * npairs;
+  DmhPair<REL> pw;
+  pw.load(params, ref, n, Q, pr, col, g, H, W, stride);
+  pw.store_prepared(ws + (size_t)blockIdx.x * (DmhPair<REL>::PREP_DWORDS * 64), lane);
+}
+
 // up [N, Q, 2H, 256] bf16, amask [N, Q, (H/SC) * (128/SC)] bytes
 template <bool REL, int SC>
-__global__ __launch_bounds__(256, 2) void dmh_fused_kernel(const float *__restrict__ feat, const float *__restrict__ ref,
-                                                           const float *__restrict__ params, const int Q, const int H,
+__global__ __launch_bounds__(256, 2) void dmh_fused_kernel(const float *__restrict__ feat,
+                                                           const unsigned *__restrict__ ws, const int Q, const int H,
                                                            const int stride, __bf16 *__restrict__ up,
                                                            unsigned char *__restrict__ amask)
 {
@@ -51,13 +65,13 @@ __global__ __launch_bounds__(256, 2) void dmh_fused_kernel(const float *__restri
   const int ht0 = 4 * (wave & 1);
 
   // ---- B operands of all tiles (tile t of a row <-> pixel x = 8 col + t), kept for all query pairs -----------------------
-  dm_s16x4 fb[FZ_TILES], cb[FZ_TILES];
+  dm_u32x4 fb[FZ_TILES];
   const float *fimg = feat + (size_t)n * C * HW;
 #pragma unroll
   for (int t = 0; t < FZ_TILES; ++t) {
     const int row = t < 8 ? y0 : (t < 16 ? y1 : hy);
     const int tt = t < 16 ? (t & 7) : ht0 + (t - 16);
-    dmh_pixel_operands<REL>(fimg, HW, W, row * W + 8 * col + tt, g, stride, fb[t], cb[t]);
+    fb[t] = dmh_pixel_operand<REL>(fimg, HW, W, row * W + 8 * col + tt, g, stride);
   }
 
   const bool top = y0 == 0;
@@ -69,21 +83,37 @@ __global__ __launch_bounds__(256, 2) void dmh_fused_kernel(const float *__restri
   const int OW = 2 * W;
   const int th_w = W / SC;                                                   // attention-mask row length
 
+#ifdef FZ_STAMP
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = 0;
+#define FZ_ST(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); __builtin_amdgcn_sched_barrier(0); if ((i) >= 0) ts[(i) < 0 ? 0 : (i)] += t_ - tp; tp = t_; } while (0)
+#else
+#define FZ_ST(i) do { } while (0)
+#endif
   const int npairs = (Q + 1) / 2;
-  typename DmhPair<REL>::Raw raw = DmhPair<REL>::fetch(params, ref, n, Q, 0, col, g);
+  // the pairs' parameters in the form the MFMAs take them, written by dmh_prepare_kernel: 5 coalesced 16-byte loads per lane
+  // and pair instead of ~40 scattered dword loads and ~100 vector instructions of splitting and packing in EACH of the
+  // image's 16 bands (a fifth of a pair's cycles before); the next pair's are in flight while this pair is computed
+  const unsigned *wsn = ws + (size_t)n * npairs * (DmhPair<REL>::PREP_DWORDS * 64);
+  typename DmhPair<REL>::Prepared prep = DmhPair<REL>::fetch_prepared(wsn, lane);
+  // The attention-mask byte of a bf16 value v is  bf16(sigmoid(v)) < 0.5.  sigmoid is monotonic and bf16(.) rounds 0.5 - x/4
+  // to 0.5 for every bf16 |x| < 2^-8 and below it for every |x| > 2^-8, so the byte is (v < -2^-8) except AT v = -2^-8, where
+  // the fp32 evaluation decides: evaluated once here with the very expression the two-launch path uses
+  const bool edge_masked = dm_mask_byte(0.5f, 0.5f, -0.00390625f, -0.00390625f, -0.00390625f, -0.00390625f) != 0;
   for (int pr = 0; pr < npairs; ++pr) {
+    FZ_ST(-1);
     DmhPair<REL> pw;
-    pw.prepare(raw, col, g, H, W, stride);
-    // the next pair's parameters: in flight while this pair is computed (the last iteration re-reads its own)
-    raw = DmhPair<REL>::fetch(params, ref, n, Q, min(pr + 1, npairs - 1), col, g);
+    pw.take(prep);
+    prep = DmhPair<REL>::fetch_prepared(wsn + (size_t)min(pr + 1, npairs - 1) * (DmhPair<REL>::PREP_DWORDS * 64), lane);
+    const int q_acc = min(2 * pr + qsel, Q - 1);
     const int buf = pr & 1;
+    FZ_ST(0);
 
     // ---- logits of my tiles, rounded to bf16 (what the two-launch path stores and reads back) -----------------------------
     unsigned pk0[4], pk1[4], pkh[2];
     {
       float lg[FZ_TILES];
 #pragma unroll
-      for (int t0 = 0; t0 < FZ_TILES; t0 += 4) pw.template tiles<4>(fb + t0, cb + t0, lg + t0);
+      for (int t0 = 0; t0 < FZ_TILES; t0 += 4) pw.template tiles<4>(fb + t0, lg + t0);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         pk0[k] = pack_bf16x2(lg[2 * k], lg[2 * k + 1]);
@@ -93,6 +123,7 @@ __global__ __launch_bounds__(256, 2) void dmh_fused_kernel(const float *__restri
       pkh[1] = pack_bf16x2(lg[18], lg[19]);
     }
 
+    FZ_ST(1);
     // ---- trade rows: group parity 0 publishes the wave's first row and its halo quarter, parity 1 the second row -------
     {
       const dm_u32x4 own = par ? dm_u32x4{pk1[0], pk1[1], pk1[2], pk1[3]} : dm_u32x4{pk0[0], pk0[1], pk0[2], pk0[3]};
@@ -100,7 +131,9 @@ __global__ __launch_bounds__(256, 2) void dmh_fused_kernel(const float *__restri
       if (!par)
         *reinterpret_cast<dm_u32x2 *>(&xch[buf][(wave >> 1) ? FZ_SLOTS - 1 : 0][qsel][8 * col + ht0]) = dm_u32x2{pkh[0], pkh[1]};
     }
+    FZ_ST(2);
     __syncthreads();
+    FZ_ST(3);
     // the row above my pair (parity 0) or below it (parity 1)
     const dm_u32x4 hal = *reinterpret_cast<const dm_u32x4 *>(&xch[buf][par ? 2 * wave + 3 : 2 * wave][qsel][8 * col]);
 
@@ -127,11 +160,12 @@ __global__ __launch_bounds__(256, 2) void dmh_fused_kernel(const float *__restri
                                                                        __builtin_bit_cast(int, e[r][1]), 0x101, 0xf, 0xf, false));
     }
 
+    FZ_ST(4);
     // ---- x2 upsample: horizontal blends of the three rows once, then the two output rows ---------------------------------
     // even output column 2 (x0 + k): source columns (x0 + k - 1, x0 + k), weights (1/4, 3/4) -- at the map's left edge
     // (1, 0) on the clamped pair; odd column: (x0 + k, x0 + k + 1), weights (3/4, 1/4)
     const bool wr = 2 * pr + qsel < Q;
-    __bf16 *uplane = up + ((size_t)n * Q + pw.q_acc) * (size_t)(4 * HW);
+    __bf16 *uplane = up + ((size_t)n * Q + q_acc) * (size_t)(4 * HW);
     float tx[3][16];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -165,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void dmh_fused_kernel(const float *__restri
       *reinterpret_cast<dm_u32x4 *>(rb + 8) = ob[1];
     }
 
+    FZ_ST(5);
     // ---- attention mask at 1 / SC of the map: target (ty, tx) reads rows SC ty + SC/2 - 1, + 1 and the same two columns,
     // all four weights 1/2.  SC = 2: my own rows (window rows 1, 2 of parity 0); SC = 4, 8: the row above + my first row
     // (window rows 0, 1), in the waves whose first row is SC/2 (mod SC).
@@ -175,32 +210,46 @@ __global__ __launch_bounds__(256, 2) void dmh_fused_kernel(const float *__restri
 #pragma unroll
       for (int j = 0; j < 8 / SC; ++j) {
         const int xl = SC * j + SC / 2 - 1;                     // pixel index inside the lane's 8 (e[][1 + xl])
-        bytes |= (unsigned)dm_mask_byte(0.5f, 0.5f, e[RA][1 + xl], e[RA][2 + xl], e[RA + 1][1 + xl], e[RA + 1][2 + xl]) << (8 * j);
+        const float v = (float)(__bf16)dm_blend(0.5f, 0.5f, 0.5f, 0.5f, e[RA][1 + xl], e[RA][2 + xl], e[RA + 1][1 + xl], e[RA + 1][2 + xl]);
+        bytes |= (unsigned)(v < -0.00390625f || (edge_masked && v == -0.00390625f)) << (8 * j);
       }
-      unsigned char *mp = amask + ((size_t)n * Q + pw.q_acc) * (size_t)((H / SC) * th_w) + (size_t)ty * th_w + (8 / SC) * col;
+      unsigned char *mp = amask + ((size_t)n * Q + q_acc) * (size_t)((H / SC) * th_w) + (size_t)ty * th_w + (8 / SC) * col;
       if constexpr (SC == 2) *reinterpret_cast<unsigned *>(mp) = bytes;
       else if constexpr (SC == 4) *reinterpret_cast<unsigned short *>(mp) = (unsigned short)bytes;
       else *mp = (unsigned char)bytes;
     }
+    FZ_ST(6);
   }
+#ifdef FZ_STAMP
+  if (blockIdx.x == 7 && threadIdx.x == 64)
+    for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long *>(amask)[i] = ts[i];
+#endif
 }
 
-// -100: geometry not covered (the caller runs the two-launch path)
+// -100: geometry not covered (the caller runs the two-launch path).  `workspace`: N * ceil(Q / 2) * 5120 bytes, 16-byte aligned.
 int launch_dyn_mask_head_fused(const float *feat, const float *ref, const float *params, int N, int C, int Q, int H, int W,
-                               int stride, int rel_coord, int th, int tw, void *up, unsigned char *amask,
+                               int stride, int rel_coord, int th, int tw, void *workspace, void *up, unsigned char *amask,
                                hipStream_t stream)
 {
   if (C != DMH_C || W != FZ_W || H < FZ_BAND || (H % FZ_BAND) != 0) return -100;
   if (th <= 0 || tw <= 0 || H % th != 0 || W % tw != 0 || H / th != W / tw) return -100;
   const int sc = H / th;
   if (sc != 2 && sc != 4 && sc != 8) return -100;
-  if ((long long)N * (H / FZ_BAND) > 0x7fffffffLL) return -100;
-  if (((uintptr_t)up & 15u) || ((uintptr_t)amask & 3u)) return -100;
+  const int npairs = (Q + 1) / 2;
+  if ((long long)N * (H / FZ_BAND) > 0x7fffffffLL || (long long)N * npairs > 0x7fffffffLL) return -100;
+  if (((uintptr_t)up & 15u) || ((uintptr_t)amask & 3u) || ((uintptr_t)workspace & 15u)) return -100;
   if (sc == 2 && (((size_t)(H / 2) * (W / 2)) & 3u)) return -100;          // 4-byte mask stores
+  unsigned *ws = static_cast<unsigned *>(workspace);
+  if (rel_coord)
+    hipLaunchKernelGGL(dmh_prepare_kernel<true>, dim3((unsigned)(N * npairs)), dim3(64), 0, stream, params, ref, Q, H, W, stride, ws);
+  else
+    hipLaunchKernelGGL(dmh_prepare_kernel<false>, dim3((unsigned)(N * npairs)), dim3(64), 0, stream, params, ref, Q, H, W, stride, ws);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
   const dim3 grid((unsigned)(N * (H / FZ_BAND))), block(256);
   __bf16 *u = static_cast<__bf16 *>(up);
 #define PCT_FZ(REL_, SC_) \
-  hipLaunchKernelGGL((dmh_fused_kernel<REL_, SC_>), grid, block, 0, stream, feat, ref, params, Q, H, stride, u, amask)
+  hipLaunchKernelGGL((dmh_fused_kernel<REL_, SC_>), grid, block, 0, stream, feat, ws, Q, H, stride, u, amask)
   if (rel_coord) {
     if (sc == 2) PCT_FZ(true, 2);
     else if (sc == 4) PCT_FZ(true, 4);

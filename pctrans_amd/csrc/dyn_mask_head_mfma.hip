@@ -41,24 +41,24 @@ __global__ __launch_bounds__(DMM_BLOCK) void dmh_logits_mfma_kernel(const float 
   const int px_base = (pb * (DMM_BLOCK / 64) + wave) * (DMM_PT * 16);
 
   // ---- B operands of layer 0 for my pixel column of each tile (kept for all query pairs; dmh_common.hpp) -------------
-  dm_s16x4 fb[DMM_PT], cb[DMM_PT];
+  dm_u32x4 fb[DMM_PT];
   const float *fimg = feat + (size_t)n * C * HW;
 #pragma unroll
   for (int t = 0; t < DMM_PT; ++t) {
     const int px = min(px_base + col * DMM_PT + t, HW - 1);        // lane `col` owns DMM_PT CONSECUTIVE pixels (one 16-B store)
-    dmh_pixel_operands<REL>(fimg, HW, W, px, g, stride, fb[t], cb[t]);
+    fb[t] = dmh_pixel_operand<REL>(fimg, HW, W, px, g, stride);
   }
 
   const int npairs = (Q + 1) / 2;
   for (int pr = 0; pr < npairs; ++pr) {
     DmhPair<REL> pw;
     pw.load(params, ref, n, Q, pr, col, g, H, W, stride);
-    __bf16 *lrow = logits + ((size_t)n * Q + pw.q_acc) * HW;
+    __bf16 *lrow = logits + ((size_t)n * Q + min(2 * pr + (g >> 1), Q - 1)) * HW;
     const bool writer = (g & 1) == 0 && 2 * pr + (g >> 1) < Q;   // groups 0 / 2 hold the reduced logit of q0 / q1
 
     float outv[DMM_PT];
-    pw.template tiles<4>(fb, cb, outv);
-    pw.template tiles<4>(fb + 4, cb + 4, outv + 4);
+    pw.template tiles<4>(fb, outv);
+    pw.template tiles<4>(fb + 4, outv + 4);
     if (writer) {                                                // the lane's 8 consecutive pixels: one 16-byte store
       const int px0 = px_base + col * DMM_PT;
       if (px0 + DMM_PT <= HW && ((HW & 7) == 0)) {

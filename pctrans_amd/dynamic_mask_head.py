@@ -53,11 +53,12 @@ def dynamic_mask_head_forward(mask_feats, ref_xy, params, stride, rel_coord, tar
     if kernel not in (None, "fused", "mfma", "valu"):
         raise RuntimeError("kernel must be None, 'fused', 'mfma' or 'valu'")
     if out_dtype == torch.bfloat16 and kernel in (None, "fused") and (kernel == "fused" or fused_geometry(H, W, (th, tw))):
-        # bf16-autocast configuration, one launch: the logits plane never goes to memory
+        # bf16-autocast configuration, one pass over the pixels: the logits plane never goes to memory
+        ws = torch.empty((N * ((Q + 1) // 2) * 1280,), dtype=torch.int32, device=mask_feats.device)   # 5120 B per pair
         with torch.cuda.device(mask_feats.device):
             rc = _lib.lib().pct_dynamic_mask_head_forward_fused_bf16(
                 feats.data_ptr(), ref.data_ptr() if rel_coord else None, prm.data_ptr(), N, C, Q, H, W, int(stride),
-                1 if rel_coord else 0, th, tw, up.data_ptr(), amask.data_ptr(),
+                1 if rel_coord else 0, th, tw, ws.data_ptr(), up.data_ptr(), amask.data_ptr(),
                 torch.cuda.current_stream(mask_feats.device).cuda_stream)
         _lib.check(rc, "dynamic_mask_head_forward_fused_bf16")
         return up, amask
