@@ -256,6 +256,20 @@ PCT_API int pct_masked_attention_bf16(const void *q, const void *k, const void *
                                       int batch, int heads, int num_query, int num_key, int head_dim,
                                       int v_head_dim, float scale, int out_dtype, void *out, void *stream);
 
+/* ---- position-guided masked cross-attention core of the decoder (MFMA, bf16 operands, fp32 accumulate) ------------
+ * The CrossAttentionLayer's own operand form (transformer_decoder/mask2former_transformer_decoder.py:130-183): per head
+ * the query / key are [content (16) | position (16)] halves from different projections, taken here as separate tensors
+ * in the projections' layout, so the per-head torch.cat passes (:160-172) and a transposed value tensor are not needed.
+ * Same result, bit for bit, as pct_masked_attention_bf16 on the concatenated operands with head_dim 32.
+ *   q_content, q_pos [Q, N, heads*16]   k_content, k_pos, v [S, N, heads*16]   bfloat16, 16-byte aligned
+ *   mask [N, Q, S] bytes, nonzero = may not attend, shared by all heads; NULL = no mask
+ *   out  [Q, N, heads*16] bfloat16
+ * Geometry: heads % 4 == 0, num_key % 64 == 0 (mask: 16-byte aligned); anything else returns PCT_ERR_UNSUPPORTED and the
+ * caller concatenates and uses pct_masked_attention_bf16.  A fully masked row yields NaN, as there. */
+PCT_API int pct_cross_attention_bf16(const void *q_content, const void *q_pos, const void *k_content, const void *k_pos,
+                                     const void *v, const unsigned char *mask, int batch, int heads, int num_query,
+                                     int num_key, float scale, void *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

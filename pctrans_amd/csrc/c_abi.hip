@@ -36,6 +36,8 @@ int launch_dyn_mask_head_fused(const float *, const float *, const float *, int,
                                void *, void *, unsigned char *, hipStream_t);
 int launch_dyn_mask_head_mfma(const float *, const float *, const float *, int, int, int, int, int, int, int, int, int,
                               void *, void *, unsigned char *, hipStream_t);
+int launch_cross_attention(const void *, const void *, const void *, const void *, const void *, const unsigned char *, int,
+                           int, int, int, float, void *, hipStream_t);
 int launch_masked_attention(const void *, const void *, const void *, const unsigned char *, int, int, int, int, int,
                             int, float, int, void *, hipStream_t);
 int launch_groupnorm_flatten(const float *, const float *, const float *, int, int, int, int, float, float *, float *,
@@ -401,6 +403,21 @@ int pct_masked_attention_bf16(const void *q, const void *k, const void *vT, cons
   if (((uintptr_t)vT | (uintptr_t)out) & 7u) return PCT_ERR_ALIGNMENT;
   return pct::launch_masked_attention(q, k, vT, mask, batch, heads, num_query, num_key, head_dim, v_head_dim, scale,
                                       out_dtype, out, static_cast<hipStream_t>(stream));
+}
+
+int pct_cross_attention_bf16(const void *q_content, const void *q_pos, const void *k_content, const void *k_pos, const void *v,
+                             const unsigned char *mask, int batch, int heads, int num_query, int num_key, float scale,
+                             void *out, void *stream)
+{
+  if (batch < 0 || heads <= 0 || num_query < 0 || num_key <= 0) return PCT_ERR_BAD_ARG;
+  if (batch == 0 || num_query == 0) return PCT_OK;
+  if (!q_content || !q_pos || !k_content || !k_pos || !v || !out) return PCT_ERR_BAD_ARG;
+  if (((uintptr_t)q_content | (uintptr_t)q_pos | (uintptr_t)k_content | (uintptr_t)k_pos | (uintptr_t)v) & 15u)
+    return PCT_ERR_ALIGNMENT;
+  if ((uintptr_t)out & 7u) return PCT_ERR_ALIGNMENT;
+  const int r = pct::launch_cross_attention(q_content, q_pos, k_content, k_pos, v, mask, batch, heads, num_query, num_key,
+                                            scale, out, static_cast<hipStream_t>(stream));
+  return r == -100 ? PCT_ERR_UNSUPPORTED : r;
 }
 
 }  // extern "C"

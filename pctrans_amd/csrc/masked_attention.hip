@@ -19,24 +19,9 @@
 // mask [N, Q, S] bytes (nonzero = may not attend; shared by the heads) or NULL, out [Q, N, heads*VD] bf16 / fp32.
 // Fully masked rows give NaN exactly like softmax over all -inf does in the reference (callers un-mask such rows
 // first, mask2former_transformer_decoder.py:561).
-#include "msda_common.hpp"
+#include "attn_common.hpp"
 
 namespace pct {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float xgroup_max(float v)
-{
-  v = fmaxf(v, __shfl_xor(v, 16));
-  return fmaxf(v, __shfl_xor(v, 32));
-}
-__device__ __forceinline__ float xgroup_sum(float v)
-{
-  v += __shfl_xor(v, 16);
-  return v + __shfl_xor(v, 32);
-}
 
 // HD: q/k head dim (32 or 16), VD = 16.  OutT: __bf16 or float.
 template <int HD, typename OutT>
@@ -76,11 +61,10 @@ __global__ __launch_bounds__(64) void masked_attention_kernel(const __bf16 *__re
   float m_run = -INFINITY, l_run = 0.f;
 
   for (int key0 = 0; key0 < S; key0 += 32) {
-    // ---- S^T tiles: keys key0 + [0,16) and key0 + [16,32) --------------------------------------------------
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    // ---- A operands of S^T: keys key0 + [0,16) and key0 + [16,32) ------------------------------------------------------
+    bf16x8 a0, a1;
     {
       const int ka = min(key0 + col, S - 1), kb = min(key0 + 16 + col, S - 1);
-      bf16x8 a0, a1;
       if constexpr (HD == 32) {
         a0 = *reinterpret_cast<const bf16x8 *>(kbase + (size_t)ka * N * E + 8 * g);
         a1 = *reinterpret_cast<const bf16x8 *>(kbase + (size_t)kb * N * E + 8 * g);
@@ -92,10 +76,8 @@ __global__ __launch_bounds__(64) void masked_attention_kernel(const __bf16 *__re
           a1 = *reinterpret_cast<const bf16x8 *>(kbase + (size_t)kb * N * E + 8 * g);
         }
       }
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qb, s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qb, s1, 0, 0, 0);
     }
-    // this lane holds, for query `col`, keys key0 + 4g + r (s0[r]) and key0 + 16 + 4g + r (s1[r])
+    // this lane holds, for query `col`, keys key0 + 4g + r (first tile) and key0 + 16 + 4g + r (second tile)
     const int kA = key0 + 4 * g, kB = key0 + 16 + 4 * g;
     unsigned mA = 0, mB = 0;
     if (mrow) {
@@ -107,36 +89,12 @@ __global__ __launch_bounds__(64) void masked_attention_kernel(const __bf16 *__re
       else
         for (int r = 0; r < 4; ++r) mB |= (kB + r < S ? (unsigned)(mrow[kB + r] != 0) : 1u) << (8 * r);
     }
-    float p0[4], p1[4];
-    float mx = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool deadA = ((mA >> (8 * r)) & 0xFFu) != 0 || kA + r >= S;
-      const bool deadB = ((mB >> (8 * r)) & 0xFFu) != 0 || kB + r >= S;
-      p0[r] = deadA ? -INFINITY : s0[r] * scale;
-      p1[r] = deadB ? -INFINITY : s1[r] * scale;
-      mx = fmaxf(mx, fmaxf(p0[r], p1[r]));
+    for (int r = 0; r < 4; ++r) {                                   // keys past the end are dead
+      if (kA + r >= S) mA |= 0xFFu << (8 * r);
+      if (kB + r >= S) mB |= 0xFFu << (8 * r);
     }
-    mx = xgroup_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    const float m_safe = m_new == -INFINITY ? 0.f : m_new;          // nothing attendable yet: keep everything 0
-    const float alpha = __expf(m_run - m_safe);                     // exp(-inf) = 0 on the first live step
-    float rs = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      p0[r] = __expf(p0[r] - m_safe);
-      p1[r] = __expf(p1[r] - m_safe);
-      rs += p0[r] + p1[r];
-    }
-    rs = xgroup_sum(rs);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] *= alpha;
-
-    // ---- O^T += V^T . P^T : k-slot 8g+j <-> key (j < 4 ? kA + j : kB + j - 4), same permutation on both operands --
-    const bf16x8 pb = {(__bf16)p0[0], (__bf16)p0[1], (__bf16)p0[2], (__bf16)p0[3],
-                       (__bf16)p1[0], (__bf16)p1[1], (__bf16)p1[2], (__bf16)p1[3]};
+    // ---- A operand of O^T += V^T . P^T : k-slot 8g+j <-> key (j < 4 ? kA + j : kB + j - 4), same permutation on both operands --
     bf16x8 va;
     if (kB + 3 < S && (S & 3) == 0) {
       const bf16x4 va0 = *reinterpret_cast<const bf16x4 *>(vrow + kA);
@@ -149,7 +107,7 @@ __global__ __launch_bounds__(64) void masked_attention_kernel(const __bf16 *__re
         va[4 + r] = vrow[min(kB + r, S - 1)];
       }
     }
-    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o, 0, 0, 0);
+    attn_step(a0, a1, qb, va, mA, mB, scale, o, m_run, l_run);
   }
 
   if (qt * 16 + col < Q) {

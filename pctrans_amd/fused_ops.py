@@ -326,3 +326,35 @@ def masked_attention(q, k, v, num_heads, attn_mask=None, v_t=None):
             hd, Ev // num_heads, float(hd) ** -0.5, 2, out.data_ptr(), torch.cuda.current_stream(q.device).cuda_stream)
     _lib.check(rc, "masked_attention")
     return out
+
+
+def cross_attention_supported(q_content, k_content, v, num_heads, attn_mask):
+    """bf16 device tensors [tokens, N, heads*16], heads % 4 == 0, S % 64 == 0, boolean mask [N,1,L,S] (or none), forward only."""
+    if not (q_content.is_cuda and q_content.dtype == torch.bfloat16 and k_content.dtype == torch.bfloat16
+            and v.dtype == torch.bfloat16):
+        return False
+    L, N, C = q_content.shape
+    S = k_content.shape[0]
+    if C != num_heads * 16 or num_heads % 4 or S % 64 or k_content.shape != (S, N, C) or v.shape != (S, N, C):
+        return False
+    if attn_mask is not None and (attn_mask.dtype != torch.bool or tuple(attn_mask.shape) != (N, 1, L, S)):
+        return False
+    return True
+
+
+def cross_attention(q_content, q_pos, k_content, k_pos, v, num_heads, attn_mask=None):
+    """softmax(mask(q k^T / sqrt(32))) v per head with q = [q_content_h | q_pos_h], k = [k_content_h | k_pos_h] (16 + 16
+    dims per head): all operands [tokens, N, heads*16] bf16 as the projections write them -> [L, N, heads*16] bf16.
+    Bit-identical to masked_attention() on the per-head concatenations (csrc/cross_attention.hip)."""
+    L, N, C = q_content.shape
+    S = k_content.shape[0]
+    qc, qp, kc, kp, vv = (t.contiguous() for t in (q_content, q_pos, k_content, k_pos, v))
+    m = attn_mask.reshape(N, L, S).contiguous() if attn_mask is not None else None
+    out = torch.empty((L, N, C), dtype=torch.bfloat16, device=qc.device)
+    with torch.cuda.device(qc.device):
+        rc = _lib.lib().pct_cross_attention_bf16(
+            qc.data_ptr(), qp.data_ptr(), kc.data_ptr(), kp.data_ptr(), vv.data_ptr(),
+            m.data_ptr() if m is not None else None, N, num_heads, L, S, 32.0 ** -0.5, out.data_ptr(),
+            torch.cuda.current_stream(qc.device).cuda_stream)
+    _lib.check(rc, "cross_attention")
+    return out

@@ -147,8 +147,10 @@ class CrossAttentionLayer(nn.Module):
                  and C // h == 16 and self.cross_attn.dropout == 0.0
                  and (memory_mask is None or (memory_mask.dtype == torch.bool
                                               and tuple(memory_mask.shape) == (bs, 1, Q, hw))))
-        if fused:
-            # V^T [N, C, HW] straight out of the projection GEMM (W . memory^T + b): the MFMA attention kernel reads
+        # the split-operand kernel takes the projections' outputs as they are: no per-head concatenation, no V^T
+        split = fused and fused_ops.cross_attention_supported(q, k, k_pos, h, memory_mask)
+        if fused and not split:
+            # V^T [N, C, HW] straight out of the projection GEMM (W . memory^T + b): the generic MFMA attention kernel reads
             # value rows per channel, so no [HW, N, C] -> [N, C, HW] transpose pass is needed
             w = self.ca_v_proj.weight
             v_t = torch.baddbmm(self.ca_v_proj.bias.view(1, C, 1), w.unsqueeze(0).expand(bs, C, C),
@@ -164,11 +166,15 @@ class CrossAttentionLayer(nn.Module):
             q_side = self.ca_qpos_sine_proj(query_sine_embed)
         else:
             q_side = q_pos
+        if split and q.dtype == torch.bfloat16 and q_side.dtype == torch.bfloat16 and v.dtype == torch.bfloat16:
+            # per head [content (hd) | position (hd)] on both sides (:160-172), formed inside the kernel
+            core = fused_ops.cross_attention(q, q_side, k, k_pos, v, h, memory_mask)
+            return self.norm2(tgt + self.dropout2(self.cross_attn.out_proj(core)))
         # per head: [content (hd) | position (hd)]
         q = torch.cat([q.view(Q, bs, h, hd), q_side.view(Q, bs, h, hd)], dim=3).view(Q, bs, 2 * C)
         k = torch.cat([k.view(hw, bs, h, hd), k_pos.view(hw, bs, h, hd)], dim=3).view(hw, bs, 2 * C)
 
-        if fused and q.dtype == torch.bfloat16 and v_t.dtype == torch.bfloat16:
+        if fused and not split and q.dtype == torch.bfloat16 and v_t.dtype == torch.bfloat16:
             core = fused_ops.masked_attention(q, k, None, h, memory_mask, v_t=v_t)
             tgt2 = self.cross_attn.out_proj(core)
         else:
