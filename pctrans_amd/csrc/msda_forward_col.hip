@@ -58,6 +58,9 @@ namespace pct {
 #ifndef PCT_COL_EARLY
 #define PCT_COL_EARLY 1       /* the second phase's windows are staged into the finest level's region as soon as that level is gathered */
 #endif
+#ifndef PCT_COL_EARLY_WAIT
+#define PCT_COL_EARLY_WAIT 1  /* the early-staged second phase is waited for with a counted vmcnt (the next item's record stays in flight) */
+#endif
 #ifndef PCT_COL_PRIO
 #define PCT_COL_PRIO 8        /* wave priorities (s_setprio): 0 = none, 8 = by part of an item as set below; 1..7: A/B variants.  A wave
                                  in its gather is served before the waves of the other workgroups that are decoding, planning or
@@ -837,7 +840,15 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       constexpr int l = col_level_of_step<L>(ll);
       if (starts_phase[l]) {
         if (ll > 0 && early_ok && phase_of[l] == 1) {
-          __syncthreads();                                                    // staged early (below): landed (vmcnt(0)) + visible
+          // staged early (below): landed + visible.  The memory counter is in order and the NEXT item's location record
+          // was requested behind that staging: wait for everything BUT those youngest loads -- a plain barrier's
+          // vmcnt(0) made every two-phase item sit through the best part of an HBM round trip here
+#if PCT_COL_EARLY_WAIT
+          if (have_n) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NGL * 4) : "memory");
+          } else
+#endif
+            __syncthreads();
         } else {
           if (ll > 0) __syncthreads();                                        // every wave is done with the pool
           stage_phase(phase_of[l]);

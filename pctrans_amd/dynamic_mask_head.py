@@ -5,7 +5,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, _timing
 
 _OUT = {torch.float32: 0, torch.bfloat16: 2}
 
@@ -55,7 +55,7 @@ def dynamic_mask_head_forward(mask_feats, ref_xy, params, stride, rel_coord, tar
     if out_dtype == torch.bfloat16 and kernel in (None, "fused") and (kernel == "fused" or fused_geometry(H, W, (th, tw))):
         # bf16-autocast configuration, one pass over the pixels: the logits plane never goes to memory
         ws = torch.empty((N * ((Q + 1) // 2) * 1280,), dtype=torch.int32, device=mask_feats.device)   # 5120 B per pair
-        with torch.cuda.device(mask_feats.device):
+        with torch.cuda.device(mask_feats.device), _timing.timed("mask_head one-pass", feats):
             rc = _lib.lib().pct_dynamic_mask_head_forward_fused_bf16(
                 feats.data_ptr(), ref.data_ptr() if rel_coord else None, prm.data_ptr(), N, C, Q, H, W, int(stride),
                 1 if rel_coord else 0, th, tw, ws.data_ptr(), up.data_ptr(), amask.data_ptr(),
@@ -65,7 +65,7 @@ def dynamic_mask_head_forward(mask_feats, ref_xy, params, stride, rel_coord, tar
     if out_dtype == torch.bfloat16 and kernel != "valu":
         # bf16-autocast configuration: MLP on MFMA + streaming resize (two launches, bf16 logits workspace)
         scratch = torch.empty((N, Q, H, W), dtype=torch.bfloat16, device=mask_feats.device)
-        with torch.cuda.device(mask_feats.device):
+        with torch.cuda.device(mask_feats.device), _timing.timed("mask_head two-launch", feats):
             rc = _lib.lib().pct_dynamic_mask_head_forward_mfma(
                 feats.data_ptr(), ref.data_ptr() if rel_coord else None, prm.data_ptr(), N, C, Q, H, W, int(stride),
                 1 if rel_coord else 0, th, tw, scratch.data_ptr(), up.data_ptr(), amask.data_ptr(),

@@ -320,7 +320,7 @@ def masked_attention(q, k, v, num_heads, attn_mask=None, v_t=None):
         m = attn_mask.expand(N, L, S) if attn_mask.dim() == 2 else attn_mask.reshape(N, L, S)
         m = m.contiguous()
     out = torch.empty((L, N, Ev), dtype=torch.bfloat16, device=q.device)
-    with torch.cuda.device(q.device):
+    with torch.cuda.device(q.device), _timing.timed("masked_attention S=%d" % S, qc):
         rc = _lib.lib().pct_masked_attention_bf16(
             qc.data_ptr(), kc.data_ptr(), vT.data_ptr(), m.data_ptr() if m is not None else None, N, num_heads, L, S,
             hd, Ev // num_heads, float(hd) ** -0.5, 2, out.data_ptr(), torch.cuda.current_stream(q.device).cuda_stream)
@@ -351,7 +351,7 @@ def cross_attention(q_content, q_pos, k_content, k_pos, v, num_heads, attn_mask=
     qc, qp, kc, kp, vv = (t.contiguous() for t in (q_content, q_pos, k_content, k_pos, v))
     m = attn_mask.reshape(N, L, S).contiguous() if attn_mask is not None else None
     out = torch.empty((L, N, C), dtype=torch.bfloat16, device=qc.device)
-    with torch.cuda.device(qc.device):
+    with torch.cuda.device(qc.device), _timing.timed("cross_attention S=%d" % S, qc):
         rc = _lib.lib().pct_cross_attention_bf16(
             qc.data_ptr(), qp.data_ptr(), kc.data_ptr(), kp.data_ptr(), vv.data_ptr(),
             m.data_ptr() if m is not None else None, N, num_heads, L, S, 32.0 ** -0.5, out.data_ptr(),
