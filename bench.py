@@ -43,6 +43,29 @@ os.environ.setdefault("MIOPEN_FIND_MODE", "1")
 # 0.38 s each at this batch (rocprofv3: naive_conv_ab_nonpacked_fwd_nhwc, 9 s of a 15 s run), and never wins
 os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
 
+
+
+def per_rank_miopen_dirs(environ=os.environ):
+    """Several ranks on one node: every rank gets its OWN MIOpen user database and kernel cache directory (set before the
+    first convolution).  With the shared default (~/.config/miopen, ~/.cache/miopen) eight ranks running a full find
+    (MIOPEN_FIND_MODE=1) at once serialise on one database file's lock and compile the same kernels into one cache.
+    Directories an operator has already set are left alone.  Returns what it set (for the JSON line / tests)."""
+    if int(environ.get("WORLD_SIZE", "1")) <= 1 or "LOCAL_RANK" not in environ:
+        return {}
+    base = os.path.join(environ.get("PCT_BENCH_MIOPEN_BASE", os.path.join("/tmp", "pct_bench_miopen_%d" % os.getuid())),
+                        "rank%s" % environ["LOCAL_RANK"])
+    made = {}
+    for var, sub in (("MIOPEN_USER_DB_PATH", "db"), ("MIOPEN_CUSTOM_CACHE_DIR", "cache")):
+        if var not in environ:
+            d = os.path.join(base, sub)
+            os.makedirs(d, exist_ok=True)
+            environ[var] = d
+            made[var] = d
+    return made
+
+
+MIOPEN_DIRS = per_rank_miopen_dirs()
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -415,6 +438,7 @@ def main():
             "warmup": args.warmup,
             "settle_steps": len(settle_ms), "settle_ms": [round(x, 2) for x in settle_ms],
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "miopen_dirs_rank0": MIOPEN_DIRS or None,
             "ms_per_step_per_rank": {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps,
                                      "ranks": [1e3 * x / args.steps for x in per_rank]},
             "higher_is_better": True,

@@ -52,6 +52,11 @@ extern "C" {
 PCT_API int pct_abi_version(void);
 /* static string for a code returned by any entry point (hipGetErrorString for >0) */
 PCT_API const char *pct_error_string(int code);
+/* static string naming what this library was built with: "experiment=0|1; target=gfx950; col: KO=00000 ...; bcol: KO=0 ...".
+ * The kernels carry compile-time A/B switches, some of them knock-outs that give WRONG RESULTS by design (timing
+ * experiments); those only compile with -DPCT_EXPERIMENT_BUILD, which shows here as experiment=1 (tests/test_abi.py
+ * asserts experiment=0 and all knock-outs off for the library the tests run on). */
+PCT_API const char *pct_build_info(void);
 
 /* ---- MSDeformAttn forward: replaces ms_deform_attn_cuda_forward (cu:25-85) ------------------------------- */
 /* fp32 / fp64: the two dtypes the reference dispatches (AT_DISPATCH_FLOATING_TYPES, cu:69). */

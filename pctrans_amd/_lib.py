@@ -15,6 +15,7 @@ _BWD_ARGS = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, 
 SYMBOLS = {
     "pct_abi_version": ([], _i),
     "pct_error_string": ([_i], ctypes.c_char_p),
+    "pct_build_info": ([], ctypes.c_char_p),
     "pct_ms_deform_attn_forward_f32": (_FWD_ARGS, _i),
     "pct_ms_deform_attn_forward_f64": (_FWD_ARGS, _i),
     "pct_ms_deform_attn_forward_f16": (_FWD_ARGS, _i),

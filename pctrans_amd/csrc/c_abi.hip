@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdio.h>
+
 #include "../../include/pctrans_hip.h"
 #include "msda_common.hpp"
 
@@ -36,6 +38,8 @@ int launch_dyn_mask_head_fused(const float *, const float *, const float *, int,
                                void *, void *, unsigned char *, hipStream_t);
 int launch_dyn_mask_head_mfma(const float *, const float *, const float *, int, int, int, int, int, int, int, int, int,
                               void *, void *, unsigned char *, hipStream_t);
+const char *msda_forward_col_build_flags();
+const char *msda_backward_col_build_flags();
 int launch_cross_attention(const void *, const void *, const void *, const void *, const void *, const unsigned char *, int,
                            int, int, int, float, void *, hipStream_t);
 int launch_masked_attention(const void *, const void *, const void *, const unsigned char *, int, int, int, int, int,
@@ -403,6 +407,23 @@ int pct_masked_attention_bf16(const void *q, const void *k, const void *vT, cons
   if (((uintptr_t)vT | (uintptr_t)out) & 7u) return PCT_ERR_ALIGNMENT;
   return pct::launch_masked_attention(q, k, vT, mask, batch, heads, num_query, num_key, head_dim, v_head_dim, scale,
                                       out_dtype, out, static_cast<hipStream_t>(stream));
+}
+
+const char *pct_build_info(void)
+{
+  static char buf[768];
+  static const bool once = [] {
+#ifdef PCT_EXPERIMENT_BUILD
+    const char *exp = "1";
+#else
+    const char *exp = "0";
+#endif
+    snprintf(buf, sizeof(buf), "experiment=%s; target=gfx950; %s; %s", exp, pct::msda_forward_col_build_flags(),
+             pct::msda_backward_col_build_flags());
+    return true;
+  }();
+  (void)once;
+  return buf;
 }
 
 int pct_cross_attention_bf16(const void *q_content, const void *q_pos, const void *k_content, const void *k_pos, const void *v,

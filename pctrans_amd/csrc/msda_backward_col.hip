@@ -55,6 +55,15 @@ namespace pct {
 #ifndef PCT_BCOL_STAMP
 #define PCT_BCOL_STAMP 0        /* diagnostic build: per-part cycle sums of wave 0 (s_memtime), tools/stamp_msda_bwd.py */
 #endif
+#if PCT_BCOL_KO && !defined(PCT_EXPERIMENT_BUILD)
+#error "PCT_BCOL_KO knock-outs give wrong results: add -DPCT_EXPERIMENT_BUILD to build one"
+#endif
+#define PCT_BSTR2(x) #x
+#define PCT_BSTR(x) PCT_BSTR2(x)
+const char *msda_backward_col_build_flags()
+{
+  return "bcol: KO=" PCT_BSTR(PCT_BCOL_KO) " PRIO=" PCT_BSTR(PCT_BCOL_PRIO) " STAMP=" PCT_BSTR(PCT_BCOL_STAMP);
+}
 
 constexpr int BCOL_BLOCK = 256;
 constexpr int BCOL_GPX = 1092;                                  // pixels per pool (= 4 mod 32: the 8 planes of one pixel start 8 banks apart)

@@ -100,6 +100,24 @@ namespace pct {
                                 (I: 7.9 -> 9.7 GB read per launch, 1.95 -> 2.14 ms); kept as a build switch */
 #endif
 
+// The knock-out switches produce WRONG RESULTS by design (timing experiments, tools/variant.sh): a library built with one
+// of them must say so -- refused unless the build declares itself an experiment, and reported by pct_build_info().
+#if (PCT_COL_KO_NOLOC || PCT_COL_KO_NOSTORE || PCT_COL_KO_NOSTAGE || PCT_COL_KO_NOGATHER || PCT_COL_KO_NOCONF) && \
+    !defined(PCT_EXPERIMENT_BUILD)
+#error "PCT_COL_KO_* knock-outs give wrong results: add -DPCT_EXPERIMENT_BUILD (tools/variant.sh does) to build one"
+#endif
+#define PCT_STR2(x) #x
+#define PCT_STR(x) PCT_STR2(x)
+const char *msda_forward_col_build_flags()
+{
+  return "col: KO=" PCT_STR(PCT_COL_KO_NOLOC) PCT_STR(PCT_COL_KO_NOSTORE) PCT_STR(PCT_COL_KO_NOSTAGE) PCT_STR(PCT_COL_KO_NOGATHER)
+         PCT_STR(PCT_COL_KO_NOCONF) " STORE_NT=" PCT_STR(PCT_COL_STORE_NT) " LOC_NT=" PCT_STR(PCT_COL_LOC_NT) " W_NT=" PCT_STR(PCT_COL_W_NT)
+         " STREAM_NT=" PCT_STR(PCT_COL_STREAM_NT) " W_LATE=" PCT_STR(PCT_COL_W_LATE) " ITEM_ORDER=" PCT_STR(PCT_COL_ITEM_ORDER)
+         " EARLY=" PCT_STR(PCT_COL_EARLY) " EARLY_WAIT=" PCT_STR(PCT_COL_EARLY_WAIT) " PRIO=" PCT_STR(PCT_COL_PRIO) "/" PCT_STR(PCT_COL_PRIO_TOP)
+         PCT_STR(PCT_COL_PRIO_PLAN) PCT_STR(PCT_COL_PRIO_L0) PCT_STR(PCT_COL_PRIO_REST) PCT_STR(PCT_COL_PRIO_FRONT) " ORDER=" PCT_STR(PCT_COL_ORDER)
+         " LOC_AT=" PCT_STR(PCT_COL_LOC_AT);
+}
+
 // Gather order of the levels (step ll -> level).  The finest level (the last one in PCTrans' pyramids) comes first; its
 // window is the largest, and the level that most often still fits beside it in the pool is the COARSEST one, so that
 // one goes second and the two middle levels share the next phase: with model-like offsets at the north-star shape

@@ -74,8 +74,20 @@ def graph_training_front(model, example_volume, warmup=3):
     are about a third of the launches and their tensor shapes depend on the crop size only.  The transformer decoder and
     the criterion stay eager: their shapes follow the matching (lengths of the matched index lists).
 
-    Call once after the model is on the device and BEFORE wrapping it in DistributedDataParallel; training inputs must keep
-    `example_volume`'s shape and dtype (another shape raises).  The modules stay registered where they are (parameters,
+    SINGLE-RANK or FROZEN-NORM models only.  The captured graphs replay the kernels that ran at capture time: a plain
+    BatchNorm inside them keeps computing PER-RANK statistics even if the module is converted to SyncBatchNorm afterwards
+    (parallel.make_parallel does that by default, as build.py:80-81), and a SyncBatchNorm cannot be captured at all (its
+    all_gather would be recorded into the graph).  So: SyncBatchNorm inside the front raises here; training-mode BatchNorm
+    inside the front raises when a process group with more than one rank is initialised; and parallel.make_parallel refuses
+    to convert the norms of a model whose front is captured.  The shipped configurations freeze the backbone's norms
+    (FrozenBN) and use GroupNorm in the pixel decoder's encoder levels, so the four-level front has no BatchNorm at all; the
+    three-level FPN stage (`NORM: SyncBN` in the yamls) does, and is only capturable on one rank.
+
+    Call once after the model is on the device and BEFORE wrapping it in DistributedDataParallel, outside autocast (the capture
+    runs the two modules as the reference does, pixel decoder in fp32; a caller's autocast context would not reach into the
+    replay, so the graphed wrappers refuse to run under one); training inputs must keep `example_volume`'s shape and dtype
+    (another shape raises).  A captured model cannot be deep-copied or pickled as a whole (its forward closures would drive the
+    ORIGINAL model's graphs): copy / save the state dict, or capture again.  The modules stay registered where they are (parameters,
     state dict, `.eval()` paths are untouched: only their training-mode forward replays the graphs); BatchNorm statistics
     moved by the capture's warm-up passes are put back.  Measured (tools/record_train_configs.py --graph-front): configs[2]
     102.4 -> 94.3 ms per step, configs[3] 129.1 -> 120.1 ms.  Returns the model."""
@@ -83,9 +95,25 @@ def graph_training_front(model, example_volume, warmup=3):
     backbone, pixel_decoder = model.backbone, head.pixel_decoder
     if "_pct_graphed" in backbone.__dict__:
         raise RuntimeError("graph_training_front: this model's front is already captured")
+    import torch.distributed as dist
+    multi_rank = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    for owner, mod in (("backbone", backbone), ("pixel_decoder", pixel_decoder)):
+        for name, m in mod.named_modules():
+            if isinstance(m, torch.nn.SyncBatchNorm):
+                raise RuntimeError("graph_training_front: %s.%s is a SyncBatchNorm -- its cross-rank all_gather cannot be "
+                                   "captured into a HIP graph; capture the front on a single-rank / frozen-norm model only"
+                                   % (owner, name))
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and multi_rank:
+                raise RuntimeError("graph_training_front: %s.%s is a BatchNorm and %d ranks are running -- the captured graphs "
+                                   "would keep per-rank statistics where the reference synchronises them (build.py:80-81); "
+                                   "the graphed front is single-rank or frozen-norm only" % (owner, name, dist.get_world_size()))
+    if torch.is_autocast_enabled():
+        raise RuntimeError("graph_training_front: call outside torch.autocast (see the docstring)")
     was_training = model.training
     model.train()
-    buffers = {n: b.detach().clone() for n, b in list(backbone.named_buffers()) + list(pixel_decoder.named_buffers())}
+    owned = [("backbone." + n, b) for n, b in backbone.named_buffers()] + \
+            [("pixel_decoder." + n, b) for n, b in pixel_decoder.named_buffers()]
+    buffers = {n: b.detach().clone() for n, b in owned}
     with torch.no_grad():
         feats = backbone(example_volume)
     keys = sorted(feats)
@@ -94,14 +122,24 @@ def graph_training_front(model, example_volume, warmup=3):
     g_bb, g_pd = torch.cuda.make_graphed_callables((bb, pd), ((example_volume.detach().clone(),), sample_feats),
                                                    num_warmup_iters=warmup)
     with torch.no_grad():                                 # the warm-up / capture passes ran BatchNorm in training mode
-        for n, b in list(backbone.named_buffers()) + list(pixel_decoder.named_buffers()):
+        for n, b in owned:                                # (keys carry the owner's prefix: the two modules may share names)
             b.copy_(buffers[n])
     eager_backbone, eager_features = backbone.forward, pixel_decoder.forward_features
     shape, dtype = tuple(example_volume.shape), example_volume.dtype
 
+    def _no_autocast():
+        if torch.is_autocast_enabled():
+            raise RuntimeError("the graphed training front was captured outside autocast and replays as captured: run it "
+                               "outside torch.autocast (the eager path would follow the caller's autocast, the replay cannot)")
+
+    def _no_copy(*_a, **_k):
+        raise RuntimeError("a model whose training front is captured (graph_training_front) cannot be deep-copied or pickled: "
+                           "its forward closures drive the original model's HIP graphs -- copy the state dict instead")
+
     def backbone_forward(volume):
         if not (backbone.training and torch.is_grad_enabled()):
             return eager_backbone(volume)
+        _no_autocast()
         if tuple(volume.shape) != shape or volume.dtype != dtype:
             raise ValueError("graph_training_front was captured for %s %s, got %s %s" % (shape, dtype, tuple(volume.shape),
                                                                                         volume.dtype))
@@ -110,6 +148,7 @@ def graph_training_front(model, example_volume, warmup=3):
     def forward_features(features):
         if not (pixel_decoder.training and torch.is_grad_enabled()):
             return eager_features(features)
+        _no_autocast()
         out = g_pd(*[features[k] for k in keys])
         return out[0], out[1], list(out[2:])
 
@@ -117,5 +156,8 @@ def graph_training_front(model, example_volume, warmup=3):
     pixel_decoder.__dict__["_pct_graphed"] = (g_pd, eager_features)
     backbone.forward = backbone_forward                   # instance attributes: the modules stay registered as they are
     pixel_decoder.forward_features = forward_features
+    for m in (backbone, pixel_decoder):
+        m.__dict__["__deepcopy__"] = _no_copy             # copy.deepcopy looks this up on the instance
+        m.__dict__["__reduce_ex__"] = _no_copy            # pickle / torch.save(model) of the whole module
     model.train(was_training)
     return model

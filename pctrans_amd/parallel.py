@@ -77,9 +77,19 @@ def init_devices(distributed=None, backend="nccl", manual_seed=None, share_gpu=F
     return device, rank, local_rank, dist.get_world_size()
 
 
+def has_graphed_front(model):
+    """True when pctrans_amd.graph.graph_training_front captured part of this model into HIP graphs."""
+    return any("_pct_graphed" in m.__dict__ for m in model.modules())
+
+
 def convert_norms(model):
     """build.py:80-81: every BatchNorm*d of the model becomes a SyncBatchNorm (the backbone's FrozenBN is not a
-    BatchNorm and stays as it is)."""
+    BatchNorm and stays as it is).  Refused for a model whose training front is captured: the graphs would go on
+    replaying the per-rank BatchNorm kernels behind the converted modules."""
+    if has_graphed_front(model) and any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in model.modules()):
+        raise RuntimeError("convert_norms: this model's training front is captured in HIP graphs (graph_training_front); "
+                           "converting its BatchNorms to SyncBatchNorm now would leave the captured kernels unsynchronised. "
+                           "Convert first and capture only norm-free / frozen-norm fronts, or do not capture.")
     return nn.SyncBatchNorm.convert_sync_batchnorm(model)
 
 
@@ -98,6 +108,9 @@ def make_parallel(model, device, parallel="DDP", norm_mode="sync_bn", find_unuse
                                                        find_unused_parameters=True)
         return nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)
     if parallel == "DP":
+        # build.py:92-96.  Single-process multi-thread replication: the library's diagnostic hooks (kernel choice override,
+        # last-kernel report, per-launch timing) are process-wide and are not meant to be flipped while DataParallel's
+        # worker threads launch; the kernels themselves keep no per-call host state.  The north-star launch is DDP.
         return nn.DataParallel(model.to(device), device_ids=list(range(torch.cuda.device_count())))
     return model.to(device)
 

@@ -32,6 +32,28 @@ def test_library_exports_every_declared_symbol():
     assert b"im2col_step" in _lib.lib().pct_error_string(-2)
 
 
+def test_library_reports_what_it_was_built_with_and_is_not_an_experiment_build():
+    """The kernels carry compile-time A/B switches, some of them knock-outs that give wrong results (timing experiments,
+    tools/variant.sh).  Those only compile with -DPCT_EXPERIMENT_BUILD; the library the tests run on must not be one."""
+    from pctrans_amd import _lib
+    info = _lib.lib().pct_build_info().decode()
+    assert info.startswith("experiment=0; target=gfx950; "), info
+    m = re.search(r"col: KO=(\d+)", info)
+    assert m and set(m.group(1)) == {"0"}, info
+    m = re.search(r"bcol: KO=(\d+)", info)
+    assert m and m.group(1) == "0", info
+    assert "STAMP=0" in info
+
+
+def test_knock_out_switches_do_not_compile_without_the_experiment_flag(tmp_path):
+    import subprocess
+    src = os.path.join(ROOT, "pctrans_amd", "csrc", "msda_forward_col.hip")
+    cmd = ["/opt/rocm/bin/hipcc", "-std=c++20", "--offload-arch=gfx950", "-fsyntax-only", "-DPCT_COL_KO_NOGATHER=1",
+           "-I", os.path.join(ROOT, "include"), src]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "PCT_EXPERIMENT_BUILD" in r.stderr, r.stderr[-400:]
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from pctrans_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -116,3 +116,53 @@ def test_bench_gpus_n_never_reports_one_rank_as_n():
     # a launcher/--gpus mismatch is an error too
     r = _run_bench({"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2")
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_convert_norms_refuses_a_model_whose_training_front_is_captured():
+    """graph_training_front captures the per-rank BatchNorm kernels; converting to SyncBatchNorm afterwards
+    (make_parallel's default, build.py:80-81) would leave them unsynchronised -- convert_norms must refuse."""
+    from pctrans_amd import parallel
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4))
+    assert not parallel.has_graphed_front(m)
+    assert isinstance(parallel.convert_norms(m)[1], torch.nn.SyncBatchNorm)
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4))
+    m[0].__dict__["_pct_graphed"] = (None, None)                 # what graph_training_front leaves on a captured module
+    assert parallel.has_graphed_front(m)
+    with pytest.raises(RuntimeError, match="captured in HIP graphs"):
+        parallel.convert_norms(m)
+    frozen = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.GroupNorm(2, 4))
+    frozen[0].__dict__["_pct_graphed"] = (None, None)
+    parallel.convert_norms(frozen)                               # nothing to convert: allowed
+
+
+def test_every_spawned_rank_gets_its_own_miopen_database_and_cache(tmp_path):
+    """eight ranks running MIOpen's full find at once must not share one user database / kernel cache.
+    bench.py sets per-rank directories at import time (before torch / MIOpen are touched) from LOCAL_RANK."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    seen = {}
+    for r in (0, 1, 7):
+        env = dict(os.environ, WORLD_SIZE="8", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="1",
+                   PCT_BENCH_MIOPEN_BASE=str(tmp_path))
+        env.pop("MIOPEN_USER_DB_PATH", None)
+        env.pop("MIOPEN_CUSTOM_CACHE_DIR", None)
+        out = subprocess.run([sys.executable, "-c", "import os, bench; print(os.environ['MIOPEN_USER_DB_PATH']); "
+                              "print(os.environ['MIOPEN_CUSTOM_CACHE_DIR'])"], cwd=ROOT, env=env, capture_output=True,
+                             text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-500:]
+        db, cache = out.stdout.strip().splitlines()[-2:]
+        assert ("rank%d" % r) in db and ("rank%d" % r) in cache and os.path.isdir(db) and os.path.isdir(cache)
+        seen[r] = (db, cache)
+    assert len({v[0] for v in seen.values()}) == 3 and len({v[1] for v in seen.values()}) == 3
+    # a single process (the driver's N = 1 run) keeps MIOpen's defaults; an operator's own setting is respected
+    env = dict(os.environ, PCT_BENCH_MIOPEN_BASE=str(tmp_path))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MIOPEN_USER_DB_PATH", "MIOPEN_CUSTOM_CACHE_DIR"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", "import os, bench; print(os.environ.get('MIOPEN_USER_DB_PATH'))"], cwd=ROOT,
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip().splitlines()[-1] == "None"
+    env = dict(os.environ, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", MIOPEN_USER_DB_PATH="/somewhere/else")
+    out = subprocess.run([sys.executable, "-c", "import os, bench; print(os.environ['MIOPEN_USER_DB_PATH'])"], cwd=ROOT,
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip().splitlines()[-1] == "/somewhere/else"

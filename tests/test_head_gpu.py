@@ -319,3 +319,36 @@ def test_graphed_training_front_gives_the_eager_step(tmp_path):
     with pytest.raises(ValueError):
         graphed.train()
         graphed(vol[:, :, :96], targets, True)
+
+
+def test_graphed_training_front_guards():
+    """the graphed front is single-rank / frozen-norm only.  SyncBatchNorm inside it raises at capture time, a
+    captured model refuses SyncBatchNorm conversion, autocast around the graphed step raises (the replay cannot follow it),
+    and a captured model cannot be deep-copied (its closures would drive the original's graphs)."""
+    import copy
+    from pctrans_amd import graph, parallel
+    from pctrans_amd.arch import maskformer as mfm
+    from pctrans_amd.arch.resnet import ResNet
+    from pctrans_amd.config import get_cfg
+    torch.manual_seed(0)
+    cfg = get_cfg(num_queries=6, norm="BN", sem_norm="BN", enc_layers=1, dec_layers=2, train_num_points=256, dataset="BBBC")
+    model = mfm.MaskFormer(**mfm.MaskFormer.from_config(cfg, ResNet(18, 3, norm="BN"))).cuda().train()
+    vol = torch.randn(2, 3, 64, 64, device="cuda")
+    synced = torch.nn.SyncBatchNorm.convert_sync_batchnorm(copy.deepcopy(model))
+    with pytest.raises(RuntimeError, match="SyncBatchNorm"):
+        graph.graph_training_front(synced, vol)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        with pytest.raises(RuntimeError, match="outside torch.autocast"):
+            graph.graph_training_front(model, vol)
+    graph.graph_training_front(model, vol)
+    assert parallel.has_graphed_front(model)
+    with pytest.raises(RuntimeError, match="captured in HIP graphs"):
+        parallel.convert_norms(model)
+    with pytest.raises(RuntimeError, match="cannot be deep-copied"):
+        copy.deepcopy(model)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        with pytest.raises(RuntimeError, match="outside torch.autocast"):
+            model.backbone(vol)
+    model.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        model.backbone(vol)                                       # the eval path is the eager one and follows autocast

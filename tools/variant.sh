@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p ab_libs/_obj_$name
 make -C pctrans_amd/csrc -j8 >/dev/null
-FL="-O3 -std=c++20 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -fvisibility=hidden -Wall -Wno-unused-result"
+FL="-DPCT_EXPERIMENT_BUILD -O3 -std=c++20 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -fvisibility=hidden -Wall -Wno-unused-result"
 objs=""
 for f in pctrans_amd/csrc/_obj/*.o; do
   b=$(basename $f .o)
