@@ -431,6 +431,56 @@ def main():
         arrays["multi_scale_%d" % i] = m_
     save("dec_pixel_decoder_l4", **arrays)
 
+    # ---- the SHIPPED geometry: three encoder levels (res3..res5) + one FPN level for res2 (msdeformattn.py:255-290, 340-350;
+    # configs/CVPPP/CVPPP-PCTrans.yaml:17-26).  The loop of forward_features -- lateral conv of res2, bilinear resize of it DOWN
+    # to the finest encoder map, sum, output conv, output ordering -- is the reference's own method body (AST, as above).  Its
+    # two convolution modules are detectron2 `Conv2d` objects in the reference (`Conv2d(..., bias=use_bias, norm=get_norm(norm,
+    # conv_dim)[, activation=F.relu])`, :262-277); detectron2 is not installed, so the wrapper below is WRITTEN HERE from
+    # detectron2's documented semantics (an nn.Conv2d that applies `norm`, then `activation`, to its output) with GroupNorm(32)
+    # = get_norm("GN"): this fixture pins the reference's loop, resize direction and output order, not detectron2.
+    class ConvNormAct(nn.Conv2d):
+        def __init__(self, *a, norm=None, activation=None, **k):
+            super().__init__(*a, **k)
+            self.norm, self.activation = norm, activation
+
+        def forward(self, x):
+            x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+            if self.norm is not None:
+                x = self.norm(x)
+            return self.activation(x) if self.activation is not None else x
+
+    class PixelDecoderBag3(nn.Module):      # the attributes the reference constructor sets for this case (:197-290)
+        def __init__(self):
+            super().__init__()
+            self.in_features = ["res2", "res3", "res4", "res5"]
+            self.transformer_in_features = ["res3", "res4", "res5"]
+            self.transformer_num_feature_levels = 3
+            self.input_proj = nn.ModuleList(
+                nn.Sequential(nn.Conv2d(chans[f], conv_dim, kernel_size=1), nn.GroupNorm(32, conv_dim))
+                for f in self.transformer_in_features[::-1])
+            self.transformer = RefEncoder(d_model=conv_dim, dropout=0.0, nhead=8, dim_feedforward=1024,
+                                          num_encoder_layers=2, num_feature_levels=3)
+            self.pe_layer = pe_mod.PositionEmbeddingSine(conv_dim // 2, normalize=True)
+            self.maskformer_num_feature_levels = 3
+            self.num_fpn_levels = 1                       # int(log2(8) - log2(4)), :257-258
+            self.adapter_1 = ConvNormAct(chans["res2"], conv_dim, kernel_size=1, bias=False, norm=nn.GroupNorm(32, conv_dim))
+            self.layer_1 = ConvNormAct(conv_dim, conv_dim, kernel_size=3, stride=1, padding=1, bias=False,
+                                       norm=nn.GroupNorm(32, conv_dim), activation=F.relu)
+            self.lateral_convs, self.output_convs = [self.adapter_1], [self.layer_1]
+    PixelDecoderBag3.forward_features = meth["MSDeformAttnPixelDecoder.forward_features"]
+    pix3 = PixelDecoderBag3().eval()
+    fill_pixel_decoder(pix3, 53)
+    g3 = torch.Generator().manual_seed(2027)      # (its own stream again)
+    feats3 = {f: torch.randn(2, chans[f], *feat_hw[f], generator=g3) for f in chans}
+    with torch.no_grad():
+        mask_features3, enc_feat3, multi3 = pix3.forward_features(feats3)
+    arrays3 = {"feat_" + f: v for f, v in feats3.items()}
+    arrays3.update(mask_features=mask_features3, transformer_encoder_features=enc_feat3,
+                   param_names=np.asarray(sorted(pix3.state_dict())))
+    for i, m_ in enumerate(multi3):
+        arrays3["multi_scale_%d" % i] = m_
+    save("dec_pixel_decoder_l3_fpn", **arrays3)
+
     class HeadBag(nn.Module):
         def __init__(self):
             super().__init__()

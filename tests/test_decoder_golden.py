@@ -304,6 +304,52 @@ def test_pixel_decoder_on_the_hip_kernels_matches_the_reference_method(golden):
                              for o in pix.forward_features(feats_g)], 1e-4)
 
 
+def _pixel_decoder3(device):
+    """The SHIPPED geometry (configs/CVPPP/CVPPP-PCTrans.yaml:17-26): three encoder levels res3..res5 and one FPN level that
+    brings res2 in (msdeformattn.py:255-290, 340-350)."""
+    from golden_params import fill_pixel_decoder
+    from pctrans_amd.layers import ShapeSpec
+    from pctrans_amd.pixel_decoder.msdeformattn import MSDeformAttnPixelDecoder
+    shapes = {k: ShapeSpec(channels=c, stride=_PIX_STRIDE[k]) for k, c in _PIX_CH.items()}
+    pix = MSDeformAttnPixelDecoder(shapes, transformer_dropout=0.0, transformer_nheads=8, transformer_dim_feedforward=1024,
+                                   transformer_enc_layers=2, conv_dim=128, mask_dim=16, norm="GN",
+                                   transformer_in_features=["res3", "res4", "res5"], common_stride=4).eval()
+    return fill_pixel_decoder(pix, 53).to(device)
+
+
+def test_pixel_decoder_fpn_stage_matches_the_reference_method(golden, cpu_reference):
+    """The FPN stage of forward_features (msdeformattn.py:340-350) -- what the shipped three-level yamls execute: lateral 1x1 of
+    res2, bilinear resize DOWN to the finest encoder map (:347), sum, 3x3 output conv + norm + ReLU, outputs (out[-1], out[0],
+    out[:3]) -- against the reference's own method body run on a bag whose two convolution wrappers the generator writes from
+    detectron2's documented Conv2d semantics (the fixture pins the loop, the resize direction and the output order, not
+    detectron2 itself); same state-dict keys (`adapter_1.*`, `layer_1.*`)."""
+    g = golden("dec_pixel_decoder_l3_fpn")
+    pix = _pixel_decoder3("cpu")
+    assert pix.num_fpn_levels == 1
+    assert sorted(pix.state_dict()) == [str(n) for n in g["param_names"]]
+    feats = {k: _t(g["feat_" + k]) for k in _PIX_CH}
+    with torch.no_grad():
+        out = pix.forward_features(feats)
+    assert tuple(out[0].shape) == tuple(g["mask_features"].shape) == (2, 128, 8, 10)      # stride 8: resized DOWN, not up
+    _check_pixel_decoder(g, out, 1e-5)
+
+
+@pytest.mark.gpu
+def test_pixel_decoder_fpn_stage_on_the_hip_kernels_matches_the_reference_method(golden):
+    """Same on the device, fp32, forward-only (the encoder on the HIP kernels, the FPN convolutions on MIOpen), <= 1e-4."""
+    g = golden("dec_pixel_decoder_l3_fpn")
+    pix = _pixel_decoder3("cuda")
+    feats = {k: _t(g["feat_" + k]).cuda() for k in _PIX_CH}
+    from pctrans_amd import _lib
+    with torch.no_grad():
+        out = pix.forward_features(feats)
+    assert _lib.lib().pct_msda_last_kernel() != 0
+    _check_pixel_decoder(g, out, 1e-4)
+    feats_g = {k: v.clone().requires_grad_() for k, v in feats.items()}
+    _check_pixel_decoder(g, [o.detach() if torch.is_tensor(o) else [m_.detach() for m_ in o]
+                             for o in pix.forward_features(feats_g)], 1e-4)
+
+
 def _head(device):
     from pctrans_amd.layers import ShapeSpec
     from pctrans_amd.meta_arch.mask_former_head import MaskFormerHead

@@ -111,7 +111,12 @@ def test_maskformer_train_step_and_eval_on_gpu():
 ])
 def test_head_runs_on_every_baseline_config_shape(name, depth, H, W, Q, levels, N):
     """BASELINE.json configs as head-level shapes (R18 / R50 channel counts, 50/100/300 queries, non-square,
-    non-power-of-two pyramids): fused path under bf16 autocast is finite and consistent with the fp32 run."""
+    non-power-of-two pyramids, the shipped three-level geometry with its FPN stage).  ALL-ELEMENT bounds:
+      * fp32: the forward-only path on the fused HIP kernels against the package's differentiable torch formulation of the
+        same modules (what runs when gradients are needed) -- every prediction within 5e-4 x scale (observed <= 1e-4);
+      * bf16 autocast (the bench's configuration): the fused path's deviation from its own fp32 run, measured against the
+        deviation the EAGER torch formulation shows under the same autocast on the same inputs (the yardstick; observed,
+        tools/calib_head_shapes.py: maxima 0.78-1.36 x the yardstick's, means 0.93-1.33 x, mask-logit signs within 1.2 %)."""
     from pctrans_amd.config import get_cfg, resnet_output_shape
     from pctrans_amd.meta_arch.mask_former_head import MaskFormerHead
     torch.manual_seed(0)
@@ -124,14 +129,30 @@ def test_head_runs_on_every_baseline_config_shape(name, depth, H, W, Q, levels, 
         p32, mf = head(feats)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             p16, _ = head(feats)
+    with torch.enable_grad():                                   # parameters require grad: the torch formulation runs
+        e32, _ = head(feats)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            e16, _ = head(feats)
     hm, wm = (H // 4, W // 4) if levels == 4 else (H // 8, W // 8)
     assert mf.shape == (N, 128, hm, wm)
     assert p32["pred_masks"].shape == (N, Q, 2 * hm, 2 * wm) and p16["pred_masks"].shape == (N, Q, 2 * hm, 2 * wm)
     assert torch.isfinite(p32["pred_masks"]).all() and torch.isfinite(p16["pred_masks"].float()).all()
     assert len(p16["aux_outputs"]) == 9 and p16["reference_points"].shape == (N, Q, 2)
-    scale = max(1.0, float(p32["pred_masks"].abs().max()))
-    close = ((p16["pred_masks"].float() - p32["pred_masks"]).abs() <= 0.15 * scale).float().mean()
-    assert float(close) > 0.85, float(close)
+    a = p32["pred_masks"]
+    scale = max(1.0, float(a.abs().max()))
+    # fp32: fused kernels == torch formulation, every element of every prediction head
+    assert float((e32["pred_masks"].detach() - a).abs().max()) <= 5e-4 * scale
+    for x, y in zip(p32["aux_outputs"], e32["aux_outputs"]):
+        assert float((y["pred_masks"].detach() - x["pred_masks"]).abs().max()) <= 5e-4 * scale
+    assert float((e32["reference_points"].detach() - p32["reference_points"]).abs().max()) <= 5e-4
+    # bf16: every element, against the eager formulation's own bf16 deviation
+    dev_f = (p16["pred_masks"].float() - a).abs() / scale
+    dev_e = (e16["pred_masks"].detach().float() - a).abs() / scale
+    assert float(dev_f.max()) <= max(1.75 * float(dev_e.max()), 0.03), (float(dev_f.max()), float(dev_e.max()))
+    assert float(dev_f.mean()) <= 1.6 * float(dev_e.mean()) + 1e-3, (float(dev_f.mean()), float(dev_e.mean()))
+    sign_f = float(((p16["pred_masks"].float() > 0) == (a > 0)).float().mean())
+    sign_e = float(((e16["pred_masks"].detach().float() > 0) == (a > 0)).float().mean())
+    assert sign_f >= sign_e - 0.025, (sign_f, sign_e)
 
 
 def test_head_forward_is_bitwise_repeatable_at_bench_geometry():
