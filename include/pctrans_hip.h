@@ -57,6 +57,13 @@ PCT_API const char *pct_error_string(int code);
  * experiments); those only compile with -DPCT_EXPERIMENT_BUILD, which shows here as experiment=1 (tests/test_abi.py
  * asserts experiment=0 and all knock-outs off for the library the tests run on). */
 PCT_API const char *pct_build_info(void);
+/* Allocates, for the CURRENT device, the small device-side pools some kernels keep for the life of the process (work-queue
+ * counters of the persistent MSDeformAttn kernels: 136 KB; per-item flag buffers of the pyramid-column backward: 64 MB).
+ * Optional -- the first launch that needs a pool allocates it lazily -- but that lazy path allocates and synchronises the
+ * device, which must not happen while ANY stream of the process is being captured into a HIP graph (a launch that finds its
+ * pool missing under capture runs on another kernel instead: pct_msda_last_kernel / pct_msda_last_bwd_kernel tell).  Call it
+ * once per device before capturing; pctrans_amd's Python wrappers do so at their first call on a device.  0 on success. */
+PCT_API int pct_prepare_device(void);
 
 /* ---- MSDeformAttn forward: replaces ms_deform_attn_cuda_forward (cu:25-85) ------------------------------- */
 /* fp32 / fp64: the two dtypes the reference dispatches (AT_DISPATCH_FLOATING_TYPES, cu:69). */

@@ -72,7 +72,9 @@ KERNEL_NAMES = {0: "none", 1: "windowed (msda_forward_win.hip)", 2: "generic (ms
 
 
 def _last_kernel():
-    """Kernel id of the forward launch just enqueued by THIS thread's call (pct_msda_last_kernel, include/pctrans_hip.h)."""
+    """Kernel id of the forward launch enqueued last BY THE PROCESS (pct_msda_last_kernel is one process-wide atomic word:
+    right for the one-thread-per-process launch the path uses, DDP; under threaded launches -- nn.DataParallel -- it may be
+    another thread's)."""
     return int(_lib.lib().pct_msda_last_kernel())
 
 
@@ -90,6 +92,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     if attn_weight.dtype != aux:
         attn_weight = attn_weight.to(aux)
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    _lib.prepare_device(value.device)
     with torch.cuda.device(value.device), _timed("forward", value, _last_kernel):
         rc = getattr(_lib.lib(), _FWD[value.dtype])(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
@@ -114,6 +117,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_value = torch.empty_like(value)
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
+    _lib.prepare_device(value.device)
     with torch.cuda.device(value.device), _timed("backward", value):
         rc = getattr(_lib.lib(), _BWD[value.dtype])(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
@@ -161,6 +165,7 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, refer
         ref = ref.contiguous()
         batch_stride = Lq * L * 2
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    _lib.prepare_device(value.device)
     with torch.cuda.device(value.device), _timed("forward", value, _last_kernel):
         rc = _lib.lib().pct_ms_deform_attn_fused_forward_f32(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), ref.data_ptr(), batch_stride,

@@ -16,6 +16,7 @@ SYMBOLS = {
     "pct_abi_version": ([], _i),
     "pct_error_string": ([_i], ctypes.c_char_p),
     "pct_build_info": ([], ctypes.c_char_p),
+    "pct_prepare_device": ([], _i),
     "pct_ms_deform_attn_forward_f32": (_FWD_ARGS, _i),
     "pct_ms_deform_attn_forward_f64": (_FWD_ARGS, _i),
     "pct_ms_deform_attn_forward_f16": (_FWD_ARGS, _i),
@@ -80,3 +81,20 @@ def check(code, what):
     if code != 0:
         msg = lib().pct_error_string(code).decode()
         raise RuntimeError("%s failed: %s (code %d)" % (what, msg, code))
+
+
+_PREPARED = set()
+
+
+def prepare_device(device):
+    """Once per device: allocate the library's per-device pools now (include/pctrans_hip.h: pct_prepare_device), unless a
+    stream capture is under way (the pools are then allocated by the first un-captured launch, as before)."""
+    import torch
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _PREPARED:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    with torch.cuda.device(idx):
+        check(lib().pct_prepare_device(), "prepare_device")
+    _PREPARED.add(idx)

@@ -38,6 +38,8 @@ int launch_dyn_mask_head_fused(const float *, const float *, const float *, int,
                                void *, void *, unsigned char *, hipStream_t);
 int launch_dyn_mask_head_mfma(const float *, const float *, const float *, int, int, int, int, int, int, int, int, int,
                               void *, void *, unsigned char *, hipStream_t);
+int prepare_win_queue_device();
+int prepare_msda_backward_col_device();
 const char *msda_forward_col_build_flags();
 const char *msda_backward_col_build_flags();
 int launch_cross_attention(const void *, const void *, const void *, const void *, const void *, const unsigned char *, int,
@@ -407,6 +409,15 @@ int pct_masked_attention_bf16(const void *q, const void *k, const void *vT, cons
   if (((uintptr_t)vT | (uintptr_t)out) & 7u) return PCT_ERR_ALIGNMENT;
   return pct::launch_masked_attention(q, k, vT, mask, batch, heads, num_query, num_key, head_dim, v_head_dim, scale,
                                       out_dtype, out, static_cast<hipStream_t>(stream));
+}
+
+int pct_prepare_device(void)
+{
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)cap;
+  const int a = pct::prepare_win_queue_device();
+  const int b = pct::prepare_msda_backward_col_device();
+  return a ? a : b;
 }
 
 const char *pct_build_info(void)

@@ -195,7 +195,12 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(unsigned *__restrict__ p
 static hipError_t zero_fill(void *ptr, const size_t bytes, hipStream_t stream)
 {
   if (bytes == 0) return hipSuccess;
-  if (((uintptr_t)ptr & 3u) || (bytes & 3u)) return hipMemsetAsync(ptr, 0, bytes, stream);   // (never for fp32 / fp64 tensors)
+#if defined(PCT_EXPERIMENT_BUILD) && defined(PCT_ZERO_BY_MEMSET)
+  return hipMemsetAsync(ptr, 0, bytes, stream);              // diagnostic build only (tools/diag_memset_node.py): the runtime's memset node
+#endif
+  // (every caller passes fp32 / fp64 tensors: 4-byte aligned, a multiple of 4 bytes.  Anything else is refused rather than
+  // handed to hipMemsetAsync, whose captured form is what this function exists to avoid)
+  if (((uintptr_t)ptr & 3u) || (bytes & 3u)) return hipErrorInvalidValue;
   const size_t words = bytes / 4;
   size_t head = ((16 - ((uintptr_t)ptr & 15u)) & 15u) / 4;
   if (head > words) head = words;

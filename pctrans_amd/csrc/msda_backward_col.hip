@@ -961,38 +961,90 @@ int msda_bwd_kernel_choice()
 // streams must not share one) and a pool handed out once each to launches recorded into a HIP graph (the pointer is baked
 // in).  nullptr: no buffer to be had (first use under stream capture, pool exhausted) -> the caller falls back.  A launch
 // with more items than a buffer holds is dealt with inside the kernels (`overflow`).
-static unsigned char *bcol_flag_buffer(hipStream_t stream)
+// Eager ring: a slot is handed to launch k and again to launch k + RING.  Launches on ONE stream are ordered, so the re-use is
+// safe there by construction; across streams it is only safe once the slot's previous launch has COMPLETED -- every slot
+// carries the stream it was last used on and an event recorded behind that launch (bcol_flag_release), and a slot whose
+// previous launch, on another stream, is still running is not handed out: the caller falls back to the windowed kernel
+// (visible through pct_msda_last_bwd_kernel()).  `prepare` = allocate only (pct_prepare_device: outside any capture, once per
+// device, so that the first backward never allocates or synchronises).
+namespace {
+constexpr int BCOL_MAX_DEV = 64, BCOL_RING = 8, BCOL_CAPTURE_POOL = 56;
+struct BcolFlagPool {
+  unsigned char *base = nullptr;
+  unsigned seq = 0, cap_used = 0;
+  hipStream_t last_stream[BCOL_RING] = {};
+  hipEvent_t done[BCOL_RING] = {};
+  bool used[BCOL_RING] = {};
+};
+std::mutex g_bcol_mu;
+BcolFlagPool g_bcol_pool[BCOL_MAX_DEV];
+}  // namespace
+
+static unsigned char *bcol_flag_buffer(hipStream_t stream, int *slot_out, const bool prepare = false)
 {
-  constexpr int MAX_DEV = 64, RING = 8, CAPTURE_POOL = 56;
-  static std::mutex mu;
-  static unsigned char *base[MAX_DEV] = {};
-  static unsigned seq[MAX_DEV] = {}, cap_used[MAX_DEV] = {};
+  *slot_out = -1;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cap) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BCOL_MAX_DEV) return nullptr;
+  bool capturing = false;
+  if (!prepare) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    capturing = cap != hipStreamCaptureStatusNone;
   }
-  const bool capturing = cap != hipStreamCaptureStatusNone;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!base[dev]) {
+  std::lock_guard<std::mutex> lock(g_bcol_mu);
+  BcolFlagPool &pl = g_bcol_pool[dev];
+  if (!pl.base) {
     if (capturing) return nullptr;                                              // (an allocation would invalidate the capture)
     void *p = nullptr;
-    const size_t bytes = (size_t)(RING + CAPTURE_POOL) * BCOL_FLAG_STRIDE;
+    const size_t bytes = (size_t)(BCOL_RING + BCOL_CAPTURE_POOL) * BCOL_FLAG_STRIDE;
     // (the memset runs on the null stream; launches may come from non-blocking streams: wait for it once)
     if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
       (void)hipGetLastError();
       if (p) (void)hipFree(p);
       return nullptr;
     }
-    base[dev] = static_cast<unsigned char *>(p);
+    for (int i = 0; i < BCOL_RING; ++i)
+      if (hipEventCreateWithFlags(&pl.done[i], hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        for (int j = 0; j < i; ++j) (void)hipEventDestroy(pl.done[j]);
+        (void)hipFree(p);
+        return nullptr;
+      }
+    pl.base = static_cast<unsigned char *>(p);
   }
+  if (prepare) return pl.base;
   if (capturing) {
-    if (cap_used[dev] >= (unsigned)CAPTURE_POOL) return nullptr;
-    return base[dev] + (size_t)(RING + cap_used[dev]++) * BCOL_FLAG_STRIDE;
+    if (pl.cap_used >= (unsigned)BCOL_CAPTURE_POOL) return nullptr;
+    return pl.base + (size_t)(BCOL_RING + pl.cap_used++) * BCOL_FLAG_STRIDE;
   }
-  return base[dev] + (size_t)(seq[dev]++ % RING) * BCOL_FLAG_STRIDE;
+  const int slot = (int)(pl.seq % BCOL_RING);
+  if (pl.used[slot] && pl.last_stream[slot] != stream && hipEventQuery(pl.done[slot]) != hipSuccess) {
+    (void)hipGetLastError();                                                    // still running on another stream: not shared
+    return nullptr;
+  }
+  ++pl.seq;
+  *slot_out = slot;
+  return pl.base + (size_t)slot * BCOL_FLAG_STRIDE;
+}
+// behind the launches that use an eager slot: remember the stream and mark the slot's completion
+static void bcol_flag_release(const int slot, hipStream_t stream)
+{
+  if (slot < 0) return;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BCOL_MAX_DEV) return;
+  std::lock_guard<std::mutex> lock(g_bcol_mu);
+  BcolFlagPool &pl = g_bcol_pool[dev];
+  pl.last_stream[slot] = stream;
+  pl.used[slot] = true;
+  if (hipEventRecord(pl.done[slot], stream) != hipSuccess) (void)hipGetLastError();
+}
+int prepare_msda_backward_col_device()
+{
+  int slot;
+  return bcol_flag_buffer(nullptr, &slot, true) ? 0 : (int)hipErrorOutOfMemory;
 }
 
 unsigned long long *win_stamp_buffer();                                      // msda_forward_win.hip (diagnostic)
@@ -1013,7 +1065,8 @@ int launch_msda_backward_col(const float *value, const int64_t *shapes, const in
   // (measured against the windowed kernel down to one 256^2-image pyramid, 43 k (query, head) pairs: 0.042 vs 0.055 ms;
   // profiles/r03_bwd_small_sizes.txt)
   if (!forced && (long long)N * S * M < 32768) return -100;
-  unsigned char *flags = bcol_flag_buffer(stream);
+  int flag_slot = -1;
+  unsigned char *flags = bcol_flag_buffer(stream, &flag_slot);
   if (!flags) return -100;
   // (PCT_BCOL_FLAG_CAP: a smaller capacity, so that a test can reach the overflow route with an oracle-sized case)
   static const int cap_env = [] { const char *e = getenv("PCT_BCOL_FLAG_CAP"); return e ? atoi(e) : 0; }();
@@ -1024,12 +1077,8 @@ int launch_msda_backward_col(const float *value, const int64_t *shapes, const in
   unsigned *queue = win_queue_slot(stream);                                    // nullptr: static item stride
 #define PCT_BCOL(L_)                                                                                                       \
   do {                                                                                                                     \
-    static const hipError_t attr_rc = hipFuncSetAttribute(                                                                 \
-        reinterpret_cast<const void *>(&msda_backward_col_kernel<L_, false>), hipFuncAttributeMaxDynamicSharedMemorySize,  \
-        160 * 1024);                                                                                                       \
-    static const hipError_t attr_rc2 = hipFuncSetAttribute(                                                                \
-        reinterpret_cast<const void *>(&msda_backward_col_kernel<L_, true>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-        160 * 1024);                                                                                                       \
+    const hipError_t attr_rc = func_attr_per_device(reinterpret_cast<const void *>(&msda_backward_col_kernel<L_, false>));  \
+    const hipError_t attr_rc2 = func_attr_per_device(reinterpret_cast<const void *>(&msda_backward_col_kernel<L_, true>));  \
     if (attr_rc != hipSuccess) return (int)attr_rc;                                                                        \
     if (attr_rc2 != hipSuccess) return (int)attr_rc2;                                                                      \
     hipLaunchKernelGGL((msda_backward_col_kernel<L_, false>), grid, block, lds, stream, grad_out, value, shapes, starts,   \
@@ -1041,7 +1090,9 @@ int launch_msda_backward_col(const float *value, const int64_t *shapes, const in
   else if (L == 4) PCT_BCOL(4);
   else PCT_BCOL(5);
 #undef PCT_BCOL
-  return (int)hipGetLastError();
+  const int rc = (int)hipGetLastError();
+  bcol_flag_release(flag_slot, stream);
+  return rc;
 }
 
 }  // namespace pct

@@ -1009,9 +1009,7 @@ int launch_msda_forward_col(const void *value, const int64_t *shapes, const int6
   float *o = static_cast<float *>(out);
 #define PCT_COL_K(L_, FU_, B_, ST_)                                                                                     \
   do {                                                                                                                  \
-    static const hipError_t attr_rc = hipFuncSetAttribute(                                                              \
-        reinterpret_cast<const void *>(&msda_forward_col_kernel<L_, FU_, B_, ST_>),                                     \
-        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                                        \
+    const hipError_t attr_rc = func_attr_per_device(reinterpret_cast<const void *>(&msda_forward_col_kernel<L_, FU_, B_, ST_>)); \
     if (attr_rc != hipSuccess) return (int)attr_rc;                                                                     \
     hipLaunchKernelGGL((msda_forward_col_kernel<L_, FU_, B_, ST_>), grid, block, lds, stream, v, shapes, starts, lc,    \
                        at, N, S, M, pool_px, o, ref, ref_batch_stride, queue, ST_ ? win_stamp_buffer() : nullptr);      \

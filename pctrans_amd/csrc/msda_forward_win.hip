@@ -584,6 +584,12 @@ unsigned *win_queue_slot(hipStream_t stream)
   return ring[dev] + 8 * (seq[dev]++ % RING);
 }
 
+int prepare_win_queue_device()
+{
+  hipStream_t null_stream = nullptr;
+  return win_queue_slot(null_stream) ? 0 : 0;      // (nullptr = queues disabled or no memory: launches then use the static stride)
+}
+
 static unsigned long long *g_stamp_buffer = nullptr;
 void set_win_stamp_buffer(void *p) { g_stamp_buffer = static_cast<unsigned long long *>(p); }
 unsigned long long *win_stamp_buffer() { return g_stamp_buffer; }

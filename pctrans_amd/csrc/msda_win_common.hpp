@@ -1,6 +1,8 @@
 // Helpers shared by the windowed-LDS MSDeformAttn kernels (msda_forward_win.hip, msda_backward_win.hip):
 // DPP moves, packed-u16 min/max wave reductions and the per-level window record.
 #pragma once
+#include <mutex>
+
 #include "msda_common.hpp"
 
 namespace pct {
@@ -78,11 +80,35 @@ __device__ __forceinline__ unsigned wave_reduce_umax(unsigned v)
   return max(max(r0, r1), max(r2, r3));
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize = 160 KB for a kernel, once per (kernel, device): a function-local
+// `static const hipError_t rc = hipFuncSetAttribute(...)` ran once per PROCESS, i.e. only for the device that happened to be
+// current at the first launch (fine for one process per GPU, wrong for a process that drives several).
+inline hipError_t func_attr_per_device(const void *fn)
+{
+  constexpr int MAXD = 64, MAXF = 64;
+  static std::mutex mu;
+  static const void *fns[MAXF] = {};
+  static unsigned long long done[MAXF] = {};                     // bit per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXD) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(mu);
+  int slot = -1;
+  for (int i = 0; i < MAXF; ++i) {
+    if (fns[i] == fn) { slot = i; break; }
+    if (!fns[i]) { fns[i] = fn; slot = i; break; }
+  }
+  if (slot >= 0 && (done[slot] >> dev) & 1ull) return hipSuccess;
+  const hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (rc == hipSuccess && slot >= 0) done[slot] |= 1ull << dev;
+  return rc;
+}
+
 // A set of 8 zeroed per-XCD work-item counters for one launch of a persistent windowed kernel (defined in
 // msda_forward_win.hip; nullptr = use the static item stride).  Protocol inside the kernels: the first round of items is
 // static (workgroup slot), every further item of XCD x is nslots + atomicAdd(queue + x, 1); every processed item costs
 // exactly one fetch, so the fetch that returns n_x - 1 is the launch's last one and zeroes the counter again.
 unsigned *win_queue_slot(hipStream_t stream);
+int prepare_win_queue_device();     // allocate the ring now (outside any capture)
 
 // One level's window, derived identically by every lane from the 4 per-wave boxes in LDS.
 struct LevelWindow {

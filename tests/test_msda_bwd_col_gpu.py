@@ -259,3 +259,34 @@ def test_backward_replays_from_a_hip_graph(MSDA, lib, kernel, sigma):
             assert float((out[0] - eager[0]).abs().max()) <= 1e-5 * scale                      # grad_value: float atomics
         again = MSDA.ms_deform_attn_backward(*args)                                            # eager launches in between
         assert float((again[0] - eager[0]).abs().max()) <= 1e-5 * scale
+
+
+def test_backward_launches_in_flight_on_several_streams_never_share_a_flag_buffer(MSDA, lib):
+    """ADVICE r3: the eager flag-buffer ring has 8 slots.  Launch k and launch k + 8 used to share one whatever their streams;
+    now a slot whose previous launch -- on ANOTHER stream -- has not completed is not handed out (that launch runs on the
+    windowed kernel instead).  24 backward launches round-robin over 4 streams without any host synchronisation: every
+    result equals the single-stream one (grad_sampling_loc / grad_attn_weight bit for bit for the launches that ran the
+    column kernel; all within the oracle tolerance)."""
+    c = make_case(seed=79, N=2, M=8, D=16, Lq=n_px(P2), P=4, shapes=P2, model_like=True, px_sigma=2.0)
+    go = grad_out_for(c, 179)
+    args = [dev(c["value"]), dev(c["shapes"]), dev(c["starts"]), dev(c["loc"]), dev(c["attn"]), dev(go), 64]
+    with force(lib, B_COL):
+        ref = MSDA.ms_deform_attn_backward(*args)
+        torch.cuda.synchronize()
+        assert lib.pct_msda_last_bwd_kernel() == B_COL
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    results, kernels = [], []
+    for i in range(24):
+        with torch.cuda.stream(streams[i % 4]):
+            results.append(MSDA.ms_deform_attn_backward(*args))          # auto: column kernel, or windowed when no slot is free
+            kernels.append(lib.pct_msda_last_bwd_kernel())
+    torch.cuda.synchronize()
+    assert set(kernels) <= {B_COL, B_WIN} and kernels.count(B_COL) >= 8, kernels
+    scale = [float(t.abs().max()) for t in ref]
+    for k, out in zip(kernels, results):
+        for j in range(3):
+            assert float((out[j] - ref[j]).abs().max()) <= 2e-5 * scale[j], (k, j)
+        if k == B_COL:
+            assert torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2])

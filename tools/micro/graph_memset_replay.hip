@@ -16,6 +16,15 @@ __global__ void add_one(float *p, size_t n)
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] += 1.0f;
 }
 
+// a kernel with as many arguments as the MSDeformAttn backward (17: ~130 bytes of kernel arguments)
+__global__ void add_one_many_args(float *p, const long *a1, const long *a2, const float *a3, const float *a4, const float *a5, int i1,
+                                  int i2, int i3, int i4, int i5, int i6, int i7, float *o1, float *o2, float *o3, size_t n)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] += 1.0f;
+  if (i1 == 12345 && o1) o1[0] = (float)(i2 + i3 + i4 + i5 + i6 + i7) + (a1 ? 1.f : 0.f) + (a2 ? 1.f : 0.f) + (a3 ? 1.f : 0.f) +
+                                 (a4 ? 1.f : 0.f) + (a5 ? 1.f : 0.f) + (o2 ? 1.f : 0.f) + (o3 ? 1.f : 0.f);
+}
+
 int main()
 {
   const size_t sizes[] = {1u << 16, 5570560, 89128960};            // floats: 256 KB, 22 MB (grad_value at batch 2), 356 MB (batch 32)
@@ -29,9 +38,17 @@ int main()
     hipGraphExec_t ge;
     hipStreamBeginCapture(s, hipStreamCaptureModeGlobal);
     hipMemsetAsync(d, 0, n * 4, s);
-    hipLaunchKernelGGL(add_one, dim3(1024), dim3(256), 0, s, d, n);
+    if (getenv("MANY_ARGS"))
+      hipLaunchKernelGGL(add_one_many_args, dim3(1024), dim3(256), 0, s, d, (const long *)nullptr, (const long *)nullptr,
+                         (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 1, 2, 3, 4, 5, 6, 7, (float *)nullptr,
+                         (float *)nullptr, (float *)nullptr, n);
+    else
+      hipLaunchKernelGGL(add_one, dim3(1024), dim3(256), 0, s, d, n);
     hipStreamEndCapture(s, &g);
-    hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (getenv("AUTO_FREE_FLAG"))                  // what torch.cuda.CUDAGraph instantiates with
+      hipGraphInstantiateWithFlags(&ge, g, hipGraphInstantiateFlagAutoFreeOnLaunch);
+    else
+      hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
     if (getenv("DESTROY_GRAPH_FIRST")) {          // torch.cuda.CUDAGraph keeps only the executable graph
       hipGraphDestroy(g);
       g = nullptr;
