@@ -275,12 +275,14 @@ PCT_API int pct_masked_attention_bf16(const void *q, const void *k, const void *
  * Same result, bit for bit, as pct_masked_attention_bf16 on the concatenated operands with head_dim 32.
  *   q_content, q_pos [Q, N, heads*16]   k_content, k_pos, v [S, N, heads*16]   bfloat16, 16-byte aligned
  *   mask [N, Q, S] bytes, nonzero = may not attend, shared by all heads; NULL = no mask
+ *   row_open [N, Q] bytes or NULL: nonzero = ignore this query's mask row (the decoder's "a query whose mask rules out every
+ *        pixel attends everywhere instead", :561, without rewriting the mask tensor)
  *   out  [Q, N, heads*16] bfloat16
  * Geometry: heads % 4 == 0, num_key % 64 == 0 (mask: 16-byte aligned); anything else returns PCT_ERR_UNSUPPORTED and the
  * caller concatenates and uses pct_masked_attention_bf16.  A fully masked row yields NaN, as there. */
 PCT_API int pct_cross_attention_bf16(const void *q_content, const void *q_pos, const void *k_content, const void *k_pos,
-                                     const void *v, const unsigned char *mask, int batch, int heads, int num_query,
-                                     int num_key, float scale, void *out, void *stream);
+                                     const void *v, const unsigned char *mask, const unsigned char *row_open, int batch,
+                                     int heads, int num_query, int num_key, float scale, void *out, void *stream);
 
 #ifdef __cplusplus
 }

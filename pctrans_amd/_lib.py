@@ -40,7 +40,7 @@ SYMBOLS = {
     "pct_groupnorm_flatten_f32": ([_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, ctypes.c_longlong,
                                    ctypes.c_longlong, _vp], _i),
     "pct_lsap_f32": ([_vp, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
-    "pct_cross_attention_bf16": ([_vp] * 6 + [_i] * 4 + [ctypes.c_float, _vp, _vp], _i),
+    "pct_cross_attention_bf16": ([_vp] * 7 + [_i] * 4 + [ctypes.c_float, _vp, _vp], _i),
     "pct_masked_attention_bf16": ([_vp, _vp, _vp, _vp] + [_i] * 6 + [ctypes.c_float, _i, _vp, _vp], _i),
     "pct_dynamic_mask_head_forward_mfma": ([_vp, _vp, _vp] + [_i] * 9 + [_vp, _vp, _vp, _vp], _i),
     "pct_dynamic_mask_head_forward_fused_bf16": ([_vp, _vp, _vp] + [_i] * 9 + [_vp, _vp, _vp, _vp], _i),

@@ -42,8 +42,8 @@ int prepare_win_queue_device();
 int prepare_msda_backward_col_device();
 const char *msda_forward_col_build_flags();
 const char *msda_backward_col_build_flags();
-int launch_cross_attention(const void *, const void *, const void *, const void *, const void *, const unsigned char *, int,
-                           int, int, int, float, void *, hipStream_t);
+int launch_cross_attention(const void *, const void *, const void *, const void *, const void *, const unsigned char *,
+                           const unsigned char *, int, int, int, int, float, void *, hipStream_t);
 int launch_masked_attention(const void *, const void *, const void *, const unsigned char *, int, int, int, int, int,
                             int, float, int, void *, hipStream_t);
 int launch_groupnorm_flatten(const float *, const float *, const float *, int, int, int, int, float, float *, float *,
@@ -438,8 +438,8 @@ const char *pct_build_info(void)
 }
 
 int pct_cross_attention_bf16(const void *q_content, const void *q_pos, const void *k_content, const void *k_pos, const void *v,
-                             const unsigned char *mask, int batch, int heads, int num_query, int num_key, float scale,
-                             void *out, void *stream)
+                             const unsigned char *mask, const unsigned char *row_open, int batch, int heads, int num_query,
+                             int num_key, float scale, void *out, void *stream)
 {
   if (batch < 0 || heads <= 0 || num_query < 0 || num_key <= 0) return PCT_ERR_BAD_ARG;
   if (batch == 0 || num_query == 0) return PCT_OK;
@@ -447,8 +447,8 @@ int pct_cross_attention_bf16(const void *q_content, const void *q_pos, const voi
   if (((uintptr_t)q_content | (uintptr_t)q_pos | (uintptr_t)k_content | (uintptr_t)k_pos | (uintptr_t)v) & 15u)
     return PCT_ERR_ALIGNMENT;
   if ((uintptr_t)out & 7u) return PCT_ERR_ALIGNMENT;
-  const int r = pct::launch_cross_attention(q_content, q_pos, k_content, k_pos, v, mask, batch, heads, num_query, num_key,
-                                            scale, out, static_cast<hipStream_t>(stream));
+  const int r = pct::launch_cross_attention(q_content, q_pos, k_content, k_pos, v, mask, mask ? row_open : nullptr, batch, heads,
+                                            num_query, num_key, scale, out, static_cast<hipStream_t>(stream));
   return r == -100 ? PCT_ERR_UNSUPPORTED : r;
 }
 

@@ -35,6 +35,8 @@ typedef unsigned xa_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned xa_u32x2 __attribute__((ext_vector_type(2)));
 
 // q_c, q_s [Q, N, heads*16]; k_c, k_p, v [S, N, heads*16] bf16; mask [N, Q, S] bytes (nonzero = may not attend) or NULL;
+// row_open [N, Q] bytes or NULL: nonzero = this query's mask row is ignored (it attends everywhere) -- the decoder's "a query
+// whose mask rules out every pixel attends everywhere instead" (dec.py:561) without re-writing the [N, Q, S] mask;
 // out [Q, N, heads*16] bf16.  S % 64 == 0, heads % 4 == 0.
 struct XaShared {
   xa_u32x4 sKc[2][XA_CH * 8], sKp[2][XA_CH * 8], sV[2][XA_CH * 8];
@@ -47,8 +49,9 @@ template <bool HAS_MASK, int NT>
 __device__ __forceinline__ void cross_attention_body(XaShared &sh, const __bf16 *__restrict__ q_c, const __bf16 *__restrict__ q_s,
                                                      const __bf16 *__restrict__ k_c, const __bf16 *__restrict__ k_p,
                                                      const __bf16 *__restrict__ v, const unsigned char *__restrict__ mask,
-                                                     const int N, const int heads, const int Q, const int S, const float scale,
-                                                     const int tgroups, __bf16 *__restrict__ out)
+                                                     const unsigned char *__restrict__ row_open, const int N, const int heads,
+                                                     const int Q, const int S, const float scale, const int tgroups,
+                                                     __bf16 *__restrict__ out)
 {
   auto &sKc = sh.sKc;
   auto &sKp = sh.sKp;
@@ -67,9 +70,11 @@ __device__ __forceinline__ void cross_attention_body(XaShared &sh, const __bf16 
 
   // ---- B operands of S^T = K . Q^T: Q[query][k-slot 8g .. 8g+7] = content dims 8g.. (g < 2) | position dims 8(g-2).. ------
   bf16x8 qb[NT];
+  unsigned keep[NT];                                     // all ones, or 0 for a query whose mask is to be ignored (row_open)
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int qi = min((tile0 + t) * 16 + col, Q - 1);
+    keep[t] = (HAS_MASK && row_open && row_open[(size_t)n * Q + qi]) ? 0u : 0xFFFFFFFFu;
     const __bf16 *src = (g < 2 ? q_c : q_s) + ((size_t)qi * N + n) * C + h * 16 + 8 * (g & 1);
     qb[t] = *reinterpret_cast<const bf16x8 *>(src);
   }
@@ -155,8 +160,8 @@ __device__ __forceinline__ void cross_attention_body(XaShared &sh, const __bf16 
         unsigned mA = 0, mB = 0;
         if constexpr (HAS_MASK) {
           const unsigned *mr = sM[buf][t * 16 + col];
-          mA = mr[(8 * j + g + m_rot) & 15];
-          mB = mr[(8 * j + 4 + g + m_rot) & 15];
+          mA = mr[(8 * j + g + m_rot) & 15] & keep[t];
+          mB = mr[(8 * j + 4 + g + m_rot) & 15] & keep[t];
         }
         attn_step(a0, a1, qb[t], va, mA, mB, scale, o[t], m_run[t], l_run[t]);
       }
@@ -184,7 +189,8 @@ template <bool HAS_MASK>
 __global__ __launch_bounds__(256, 2) void cross_attention_kernel(const __bf16 *__restrict__ q_c, const __bf16 *__restrict__ q_s,
                                                                  const __bf16 *__restrict__ k_c, const __bf16 *__restrict__ k_p,
                                                                  const __bf16 *__restrict__ v,
-                                                                 const unsigned char *__restrict__ mask, const int N,
+                                                                 const unsigned char *__restrict__ mask,
+                                                                 const unsigned char *__restrict__ row_open, const int N,
                                                                  const int heads, const int Q, const int S, const float scale,
                                                                  const int tgroups, __bf16 *__restrict__ out)
 {
@@ -193,16 +199,16 @@ __global__ __launch_bounds__(256, 2) void cross_attention_kernel(const __bf16 *_
   const int tg = (int)(lb % (unsigned)tgroups);
   const int ntile = min(XA_T, (Q + 15) / 16 - tg * XA_T);            // uniform over the workgroup
   static_assert(XA_T == 4, "dispatch below");
-  if (ntile == 4) cross_attention_body<HAS_MASK, 4>(sh, q_c, q_s, k_c, k_p, v, mask, N, heads, Q, S, scale, tgroups, out);
-  else if (ntile == 3) cross_attention_body<HAS_MASK, 3>(sh, q_c, q_s, k_c, k_p, v, mask, N, heads, Q, S, scale, tgroups, out);
-  else if (ntile == 2) cross_attention_body<HAS_MASK, 2>(sh, q_c, q_s, k_c, k_p, v, mask, N, heads, Q, S, scale, tgroups, out);
-  else cross_attention_body<HAS_MASK, 1>(sh, q_c, q_s, k_c, k_p, v, mask, N, heads, Q, S, scale, tgroups, out);
+  if (ntile == 4) cross_attention_body<HAS_MASK, 4>(sh, q_c, q_s, k_c, k_p, v, mask, row_open, N, heads, Q, S, scale, tgroups, out);
+  else if (ntile == 3) cross_attention_body<HAS_MASK, 3>(sh, q_c, q_s, k_c, k_p, v, mask, row_open, N, heads, Q, S, scale, tgroups, out);
+  else if (ntile == 2) cross_attention_body<HAS_MASK, 2>(sh, q_c, q_s, k_c, k_p, v, mask, row_open, N, heads, Q, S, scale, tgroups, out);
+  else cross_attention_body<HAS_MASK, 1>(sh, q_c, q_s, k_c, k_p, v, mask, row_open, N, heads, Q, S, scale, tgroups, out);
 }
 
 // -100: geometry not covered (the caller concatenates the halves and uses pct_masked_attention_bf16)
 int launch_cross_attention(const void *q_c, const void *q_s, const void *k_c, const void *k_p, const void *v,
-                           const unsigned char *mask, int N, int heads, int Q, int S, float scale, void *out,
-                           hipStream_t stream)
+                           const unsigned char *mask, const unsigned char *row_open, int N, int heads, int Q, int S,
+                           float scale, void *out, hipStream_t stream)
 {
   if (heads <= 0 || heads % XA_HG != 0 || S <= 0 || S % XA_CH != 0) return -100;
   if (N == 0 || Q == 0) return 0;
@@ -217,11 +223,11 @@ int launch_cross_attention(const void *q_c, const void *q_s, const void *k_c, co
   const __bf16 *kc = static_cast<const __bf16 *>(k_c), *kp = static_cast<const __bf16 *>(k_p);
   const __bf16 *vv = static_cast<const __bf16 *>(v);
   if (mask)
-    hipLaunchKernelGGL(cross_attention_kernel<true>, grid, block, 0, stream, qc, qs, kc, kp, vv, mask, N, heads, Q, S, scale,
-                       tgroups, static_cast<__bf16 *>(out));
+    hipLaunchKernelGGL(cross_attention_kernel<true>, grid, block, 0, stream, qc, qs, kc, kp, vv, mask, row_open, N, heads, Q, S,
+                       scale, tgroups, static_cast<__bf16 *>(out));
   else
-    hipLaunchKernelGGL(cross_attention_kernel<false>, grid, block, 0, stream, qc, qs, kc, kp, vv, mask, N, heads, Q, S, scale,
-                       tgroups, static_cast<__bf16 *>(out));
+    hipLaunchKernelGGL(cross_attention_kernel<false>, grid, block, 0, stream, qc, qs, kc, kp, vv, mask, row_open, N, heads, Q, S,
+                       scale, tgroups, static_cast<__bf16 *>(out));
   return (int)hipGetLastError();
 }
 

@@ -112,8 +112,11 @@ __global__ __launch_bounds__(256, 2) void dmh_fused_kernel(const float *__restri
     unsigned pk0[4], pk1[4], pkh[2];
     {
       float lg[FZ_TILES];
+#ifndef FZ_BATCH
+#define FZ_BATCH 4
+#endif
 #pragma unroll
-      for (int t0 = 0; t0 < FZ_TILES; t0 += 4) pw.template tiles<4>(fb + t0, lg + t0);
+      for (int t0 = 0; t0 < FZ_TILES; t0 += FZ_BATCH) pw.template tiles<FZ_BATCH>(fb + t0, lg + t0);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         pk0[k] = pack_bf16x2(lg[2 * k], lg[2 * k + 1]);

@@ -342,19 +342,25 @@ def cross_attention_supported(q_content, k_content, v, num_heads, attn_mask):
     return True
 
 
-def cross_attention(q_content, q_pos, k_content, k_pos, v, num_heads, attn_mask=None):
+def cross_attention(q_content, q_pos, k_content, k_pos, v, num_heads, attn_mask=None, row_open=None):
     """softmax(mask(q k^T / sqrt(32))) v per head with q = [q_content_h | q_pos_h], k = [k_content_h | k_pos_h] (16 + 16
     dims per head): all operands [tokens, N, heads*16] bf16 as the projections write them -> [L, N, heads*16] bf16.
-    Bit-identical to masked_attention() on the per-head concatenations (csrc/cross_attention.hip)."""
+    Bit-identical to masked_attention() on the per-head concatenations (csrc/cross_attention.hip).  `row_open`: bool [N, L] (or
+    anything reshapeable to it), True = that query ignores its mask row -- same result as attn_mask & ~row_open[..., None]
+    without writing that tensor."""
     L, N, C = q_content.shape
     S = k_content.shape[0]
     qc, qp, kc, kp, vv = (t.contiguous() for t in (q_content, q_pos, k_content, k_pos, v))
     m = attn_mask.reshape(N, L, S).contiguous() if attn_mask is not None else None
+    ro = row_open.reshape(N, L).contiguous() if (row_open is not None and m is not None) else None
+    if ro is not None and ro.dtype != torch.bool:
+        raise RuntimeError("row_open must be a bool tensor")
     out = torch.empty((L, N, C), dtype=torch.bfloat16, device=qc.device)
     with torch.cuda.device(qc.device), _timing.timed("cross_attention S=%d" % S, qc):
         rc = _lib.lib().pct_cross_attention_bf16(
             qc.data_ptr(), qp.data_ptr(), kc.data_ptr(), kp.data_ptr(), vv.data_ptr(),
-            m.data_ptr() if m is not None else None, N, num_heads, L, S, 32.0 ** -0.5, out.data_ptr(),
+            m.data_ptr() if m is not None else None, ro.data_ptr() if ro is not None else None, N, num_heads, L, S,
+            32.0 ** -0.5, out.data_ptr(),
             torch.cuda.current_stream(qc.device).cuda_stream)
     _lib.check(rc, "cross_attention")
     return out

@@ -131,7 +131,11 @@ class CrossAttentionLayer(nn.Module):
 
     def forward_post(self, tgt, memory, memory_mask: Optional[Tensor] = None,
                      memory_key_padding_mask: Optional[Tensor] = None, pos: Optional[Tensor] = None,
-                     query_pos: Optional[Tensor] = None, query_sine_embed=None, is_first=False):
+                     query_pos: Optional[Tensor] = None, query_sine_embed=None, is_first=False,
+                     memory_row_open: Optional[Tensor] = None):
+        """`memory_row_open` (bool [N, 1, Q, 1] or None): queries whose row of `memory_mask` is to be ignored (the decoder's
+        "a query whose mask rules out every pixel attends everywhere", :561).  The split-operand kernel takes it as it is;
+        every other path folds it into the mask first."""
         Q, bs, C = tgt.shape
         hw = memory.shape[0]
         h, hd = self.nhead, C // self.nhead
@@ -149,6 +153,9 @@ class CrossAttentionLayer(nn.Module):
                                               and tuple(memory_mask.shape) == (bs, 1, Q, hw))))
         # the split-operand kernel takes the projections' outputs as they are: no per-head concatenation, no V^T
         split = fused and fused_ops.cross_attention_supported(q, k, k_pos, h, memory_mask)
+        if memory_row_open is not None and memory_mask is not None and not split:
+            memory_mask = memory_mask & ~memory_row_open
+            memory_row_open = None
         if fused and not split:
             # V^T [N, C, HW] straight out of the projection GEMM (W . memory^T + b): the generic MFMA attention kernel reads
             # value rows per channel, so no [HW, N, C] -> [N, C, HW] transpose pass is needed
@@ -168,8 +175,10 @@ class CrossAttentionLayer(nn.Module):
             q_side = q_pos
         if split and q.dtype == torch.bfloat16 and q_side.dtype == torch.bfloat16 and v.dtype == torch.bfloat16:
             # per head [content (hd) | position (hd)] on both sides (:160-172), formed inside the kernel
-            core = fused_ops.cross_attention(q, q_side, k, k_pos, v, h, memory_mask)
+            core = fused_ops.cross_attention(q, q_side, k, k_pos, v, h, memory_mask, row_open=memory_row_open)
             return self.norm2(tgt + self.dropout2(self.cross_attn.out_proj(core)))
+        if memory_row_open is not None and memory_mask is not None:
+            memory_mask = memory_mask & ~memory_row_open
         # per head: [content (hd) | position (hd)]
         q = torch.cat([q.view(Q, bs, h, hd), q_side.view(Q, bs, h, hd)], dim=3).view(Q, bs, 2 * C)
         k = torch.cat([k.view(hw, bs, h, hd), k_pos.view(hw, bs, h, hd)], dim=3).view(hw, bs, 2 * C)
@@ -435,10 +444,10 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
 
             level_index = i % self.num_feature_levels
             # a query whose mask rules out every pixel attends everywhere instead (:561)
-            attn_mask = attn_mask & ~attn_mask.all(dim=-1, keepdim=True)
             output = self.transformer_cross_attention_layers[i](
                 output, src[level_index], memory_mask=attn_mask, memory_key_padding_mask=None,
-                pos=pos[level_index], query_pos=query_embed, query_sine_embed=query_sine_embed, is_first=(i == 0))
+                pos=pos[level_index], query_pos=query_embed, query_sine_embed=query_sine_embed, is_first=(i == 0),
+                memory_row_open=attn_mask.all(dim=-1, keepdim=True))
             output = self.transformer_self_attention_layers[i](
                 output, tgt_mask=None, tgt_key_padding_mask=None, query_pos=query_embed)
             output = self.transformer_ffn_layers[i](output)

@@ -65,6 +65,30 @@ def test_fully_masked_rows_give_nan_like_the_softmax_of_all_minus_infinity():
     assert torch.isnan(got[5]).all() and torch.isfinite(got[:5]).all() and torch.isfinite(got[6:]).all()
 
 
+@pytest.mark.parametrize("L,S,N,heads", [(100, 1024, 3, 8), (300, 256, 2, 8), (37, 64, 1, 4)])
+def test_row_open_equals_clearing_those_mask_rows(L, S, N, heads):
+    """The decoder's rule (:561) as a per-query flag: bit-identical to the mask with those rows cleared, for rows that are
+    fully masked (the decoder's use), partly masked, and with no flag set at all."""
+    from pctrans_amd import fused_ops
+    qc, qp, kc, kp, v = _operands(L, S, N, heads, seed=7 + L)
+    gm = torch.Generator(device="cuda").manual_seed(L * S)
+    mask = torch.rand(N, 1, L, S, device="cuda", generator=gm) < 0.6
+    mask[..., 3] = False
+    mask[0, 0, 4, :] = True                                 # fully masked rows: first tile, last (partial) tile
+    mask[N - 1, 0, L - 1, :] = True
+    row_open = mask.all(dim=-1, keepdim=True)
+    row_open[0, 0, 9, 0] = True                             # and a partly masked row opened as well
+    assert int(row_open.sum()) == 3
+    got = fused_ops.cross_attention(qc, qp, kc, kp, v, heads, mask, row_open=row_open)
+    want = fused_ops.cross_attention(qc, qp, kc, kp, v, heads, mask & ~row_open)
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    none = fused_ops.cross_attention(qc, qp, kc, kp, v, heads, mask & ~row_open, row_open=torch.zeros_like(row_open))
+    assert torch.equal(none.view(torch.int16), want.view(torch.int16))
+    with pytest.raises(RuntimeError, match="bool"):
+        fused_ops.cross_attention(qc, qp, kc, kp, v, heads, mask, row_open=row_open.to(torch.uint8))
+
+
 def test_geometry_contract():
     from pctrans_amd import fused_ops
     qc, qp, kc, kp, v = _operands(10, 96, 1, 8, seed=2)                   # 96 keys: not a multiple of 64

@@ -15,7 +15,7 @@ class A:
     image, queries, levels, dtype = 512, 100, 4, "bf16"
 
 
-def timed(fn, n=20):
+def timed(fn, n=10):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -28,7 +28,7 @@ def timed(fn, n=20):
 
 args = A()
 dev = torch.device("cuda", 0)
-for batch in (1, 2, 8):
+for batch in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("1", "2", "8"))]:
     args.batch = batch
     head, shapes = bench.build_head(args, dev)
     feats = bench.synth_features(shapes, batch, args.image, dev, 1)
