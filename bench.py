@@ -361,23 +361,28 @@ def main():
 
     for _ in range(2):          # untimed pre-warm: MIOpen's first-call kernel search for the 3x3 convolutions
         step()
-    # ... and until the step time has settled: as the first GPU process on a fresh box the first ~8 steps run 15-20 % slower
-    # than the steady state (measured: 137 ms per step with 5 untimed steps in front, 114.0 with 12, on the same boxes the
-    # second run of the same command gave 113.6).  Bounded: at most 12 more untimed steps; no collective inside.
-    # With several ranks the count is FIXED (12): a data-dependent exit would let ranks enter the timed region after different
-    # numbers of steps.  The steps taken and their times go into the JSON line (settle_steps / settle_ms).
+    # ... and until the SUSTAINED step time has settled.  Measured on this pool (round 4, tools/diag_fresh_box.py and the
+    # step_ms list below): in three of five first runs on a fresh box two steps about one second into the back-to-back load
+    # took 325 ms instead of 106 (a one-off stall of ~440 ms, the same kernels, gone in the next process on that box) while
+    # single steps bracketed by synchronisations had already settled at 106 ms -- so the settling is judged on BLOCKS of 5
+    # back-to-back steps, the way the timed region runs: at least 3 blocks, until two consecutive blocks agree within 1.5 %,
+    # at most 8 (40 untimed steps, ~4 s).  With several ranks the count is FIXED (4 blocks): a data-dependent exit would let
+    # ranks enter the timed region after different numbers of steps.  Blocks taken and their per-step times go into the JSON
+    # line (settle_steps / settle_ms); no collective inside.
+    SETTLE_BLOCK = 5
     prev = None
     settle_ms = []
-    for _ in range(12):
+    for i_blk in range(8 if world == 1 else 4):
         torch.cuda.synchronize(device)
         t_s = time.perf_counter()
-        step()
+        for _ in range(SETTLE_BLOCK):
+            step()
         torch.cuda.synchronize(device)
-        dt = time.perf_counter() - t_s
+        dt = (time.perf_counter() - t_s) / SETTLE_BLOCK
         settle_ms.append(1e3 * dt)
-        if world == 1 and prev is not None and abs(dt - prev) <= 0.015 * prev and abs(dt - prev2) <= 0.03 * prev:
+        if world == 1 and i_blk >= 2 and prev is not None and abs(dt - prev) <= 0.015 * prev:
             break
-        prev2, prev = (prev if prev is not None else dt), dt
+        prev = dt
     for _ in range(args.warmup):
         step()
 
@@ -390,10 +395,14 @@ def main():
     MSDA.kernel_timing(True)           # HIP events around every MSDeformAttn launch, on the launch stream
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    step_marks[0].record()
+    for i_step in range(args.steps):
         pred = step()
+        step_marks[i_step + 1].record()       # one event per step: a straggler step shows in the JSON (step_ms)
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = [step_marks[i].elapsed_time(step_marks[i + 1]) for i in range(args.steps)]
     launches = MSDA.kernel_timing(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else device)
@@ -436,7 +445,8 @@ def main():
             "backend": dist.get_backend() if world > 1 else None,
             "steps": args.steps,
             "warmup": args.warmup,
-            "settle_steps": len(settle_ms), "settle_ms": [round(x, 2) for x in settle_ms],
+            "settle_steps": SETTLE_BLOCK * len(settle_ms), "settle_ms": [round(x, 2) for x in settle_ms],
+            "step_ms": [round(x, 2) for x in step_ms],
             "ms_per_step": 1e3 * elapsed / args.steps,
             "miopen_dirs_rank0": MIOPEN_DIRS or None,
             "ms_per_step_per_rank": {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps,

@@ -104,6 +104,28 @@ PCT_API int pct_ms_deform_attn_fused_forward_f32(const float *value, const int64
                                                  int channels, int num_levels, int num_query, int num_point,
                                                  float *output, void *stream);
 
+/* ---- MSDeformAttn forward on PIECE-PLANE operands (new entry point, same result bit for bit) ------------------
+ * An MI355X-native operand layout for callers that control the producers (PCTrans' encoder layer does: the three
+ * projections that feed the op, ops/modules/ms_deform_attn.py:96-110, are written by pct_linear_k128_planes_f32 below).
+ * A "piece" is four consecutive floats of a (query, head) record; per image a tensor is stored as
+ *     planes[num_heads * pieces][spatial_size][4]        plane = head * pieces + piece
+ *   value_planes  pieces = channels / 4      (value[n][s][head][4 * piece ..])
+ *   loc_planes    pieces = num_levels * num_point * 2 / 4   (sampling_loc[n][q][head] flattened, or with ref_points: offsets)
+ *   attn_planes   pieces = num_levels * num_point / 4       (attn_weight[n][q][head] flattened, or with ref_points: logits)
+ *   ref_points    NULL: loc / attn are sampling locations and attention weights (the op above);
+ *                 else [batch or 1, num_query, num_levels, 2] and loc / attn are raw offsets and logits (the fused entry)
+ *   output        [batch, num_query, num_heads * channels], as above
+ * so that the 64 lanes of a wavefront read whole 128-byte lines wherever they read (records, window staging) and no
+ * register transposition is needed.  Supported: what the pyramid-column kernel covers -- num_query == spatial_size,
+ * channels == 16, num_point == 4, 3 <= num_levels <= 5, 16-byte aligned tensors; otherwise PCT_ERR_UNSUPPORTED (callers
+ * keep the reference layout and use the entries above). */
+PCT_API int pct_ms_deform_attn_forward_planes_f32(const float *value_planes, const int64_t *spatial_shapes,
+                                                  const int64_t *level_start, const float *loc_planes,
+                                                  const float *attn_planes, const float *ref_points,
+                                                  long long ref_batch_stride, int batch, int spatial_size, int num_heads,
+                                                  int channels, int num_levels, int num_query, int num_point,
+                                                  float *output, void *stream);
+
 /* ---- MSDeformAttn backward: replaces ms_deform_attn_cuda_backward (cu:88-158) ----------------------------- */
 /* grad_value [as value], grad_sampling_loc [as sampling_loc], grad_attn_weight [as attn_weight]; all three are
  * fully defined on return (grad_value is zero-filled on `stream` by a kernel of the library before the scatter-add -- not

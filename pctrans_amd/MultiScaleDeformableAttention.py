@@ -175,6 +175,75 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, refer
     return out
 
 
+def to_planes(t, num_heads):
+    """[N, S, num_heads * C] (or [N, S, num_heads, ...] with C trailing elements per head) -> the piece-plane layout
+    [N, num_heads * C / 4, S, 4] of pct_ms_deform_attn_forward_planes_f32 (a copy; the encoder layer's projection GEMM writes
+    this layout directly, this helper is for tests and tools)."""
+    N, S = t.shape[0], t.shape[1]
+    x = t.reshape(N, S, num_heads, -1)
+    C = x.shape[3]
+    if C % 4:
+        raise RuntimeError("to_planes: elements per head must be a multiple of 4")
+    return x.reshape(N, S, num_heads * (C // 4), 4).permute(0, 2, 1, 3).contiguous()
+
+
+def from_planes(p, num_heads):
+    """Inverse of to_planes: [N, num_heads * C / 4, S, 4] -> [N, S, num_heads, C]."""
+    N, NP, S, _ = p.shape
+    return p.permute(0, 2, 1, 3).reshape(N, S, num_heads, (NP // num_heads) * 4).contiguous()
+
+
+def planes_forward_supported(N, S, M, D, L, Lq, P, dtype=torch.float32):
+    """Geometry pct_ms_deform_attn_forward_planes_f32 covers (the pyramid-column kernel's)."""
+    return (dtype == torch.float32 and D == 16 and P == 4 and 3 <= L <= 5 and Lq == S and S < (1 << 24)
+            and S * M * L * P * 8 < 2 ** 31 - 1 and N * (S + 4096) * M < 2 ** 31 - 1)
+
+
+def ms_deform_attn_forward_planes(value_planes, spatial_shapes, level_start_index, loc_planes, attn_planes, num_heads,
+                                  reference_points=None):
+    """The sampling op on PIECE-PLANE operands (include/pctrans_hip.h): value_planes [N, M*4, S, 4], loc_planes
+    [N, M*L*P/2, S, 4], attn_planes [N, M*L*P/4, S, 4] fp32 -> [N, S, M*16], bit-identical to ms_deform_attn_forward /
+    ms_deform_attn_fused_forward on the same numbers in the reference layout.  `reference_points` None: locations and
+    weights; [N or 1, S, L, 2]: raw offsets and logits (the fused front-end).  Forward only."""
+    _check_inputs([("value_planes", value_planes), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("loc_planes", loc_planes), ("attn_planes", attn_planes)])
+    N, VP, S, four = value_planes.shape
+    M, L = int(num_heads), spatial_shapes.shape[0]
+    if four != 4 or VP % M or loc_planes.dim() != 4 or attn_planes.dim() != 4:
+        raise RuntimeError("ms_deform_attn_forward_planes: operands must be [N, planes, S, 4]")
+    D = VP // M * 4
+    P = attn_planes.shape[1] * 4 // (M * L)
+    if (tuple(loc_planes.shape) != (N, M * L * P // 2, S, 4) or tuple(attn_planes.shape) != (N, M * L * P // 4, S, 4)
+            or P * M * L != attn_planes.shape[1] * 4):
+        raise RuntimeError("ms_deform_attn_forward_planes: inconsistent shapes")
+    if any(t.dtype != torch.float32 for t in (value_planes, loc_planes, attn_planes)):
+        raise RuntimeError("ms_deform_attn_forward_planes: float32 operands only")
+    if not planes_forward_supported(N, S, M, D, L, S, P):
+        raise RuntimeError("ms_deform_attn_forward_planes: unsupported geometry (use the reference layout)")
+    ref, batch_stride = None, 0
+    if reference_points is not None:
+        ref = reference_points
+        if ref.dtype != torch.float32 or not ref.is_cuda:
+            raise RuntimeError("reference_points must be a float32 device tensor")
+        if tuple(ref.shape[1:]) != (S, L, 2) or ref.shape[0] not in (1, N):
+            raise RuntimeError("reference_points must be [N or 1, S, L, 2]")
+        if ref.stride()[1:] != (L * 2, 2, 1):
+            ref = ref.contiguous()
+        batch_stride = 0 if (ref.shape[0] == 1 or ref.stride(0) == 0) else ref.stride(0)
+        if batch_stride not in (0, S * L * 2):
+            ref = ref.contiguous()
+            batch_stride = S * L * 2
+    out = torch.empty((N, S, M * D), dtype=torch.float32, device=value_planes.device)
+    _lib.prepare_device(value_planes.device)
+    with torch.cuda.device(value_planes.device), _timed("forward", value_planes, _last_kernel):
+        rc = _lib.lib().pct_ms_deform_attn_forward_planes_f32(
+            value_planes.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), loc_planes.data_ptr(),
+            attn_planes.data_ptr(), ref.data_ptr() if ref is not None else None, batch_stride, N, S, M, D, L, S, P,
+            out.data_ptr(), _stream(value_planes))
+    _lib.check(rc, "ms_deform_attn_forward_planes")
+    return out
+
+
 def install_as_extension():
     """Register this module under the top-level name the reference imports
     (`import MultiScaleDeformableAttention as MSDA`, OPS/functions/ms_deform_attn_func.py:21-22)."""

@@ -24,6 +24,7 @@ SYMBOLS = {
     "pct_ms_deform_attn_backward_f32": (_BWD_ARGS, _i),
     "pct_ms_deform_attn_backward_f64": (_BWD_ARGS, _i),
     "pct_ms_deform_attn_fused_forward_f32": ([_vp, _vp, _vp, _vp, ctypes.c_longlong, _vp, _vp] + [_i] * 7 + [_vp, _vp], _i),
+    "pct_ms_deform_attn_forward_planes_f32": ([_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong] + [_i] * 7 + [_vp, _vp], _i),
     "pct_add_layernorm_f32": ([_vp, _vp, _vp, _vp, ctypes.c_float, ctypes.c_longlong, _i, _vp, _vp], _i),
     "pct_linear_k128_f32": ([_vp, ctypes.c_longlong, _vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _vp, ctypes.c_longlong, _i, _i, _vp,
                              ctypes.c_longlong, _vp], _i),

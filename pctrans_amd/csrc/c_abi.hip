@@ -42,6 +42,8 @@ int prepare_win_queue_device();
 int prepare_msda_backward_col_device();
 const char *msda_forward_col_build_flags();
 const char *msda_backward_col_build_flags();
+int launch_msda_forward_planes(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int, int,
+                               int, int, int, void *, hipStream_t, const float *, long long);
 int launch_cross_attention(const void *, const void *, const void *, const void *, const void *, const unsigned char *,
                            const unsigned char *, int, int, int, int, float, void *, hipStream_t);
 int launch_masked_attention(const void *, const void *, const void *, const unsigned char *, int, int, int, int, int,
@@ -208,6 +210,32 @@ int pct_ms_deform_attn_fused_forward_f32(const float *value, const int64_t *spat
         value + b0 * S * M * D, spatial_shapes, level_start, offsets + b0 * Lq * M * L * P * 2, attn_logits + b0 * Lq * M * L * P,
         n, spatial_size, num_heads, channels, num_levels, num_query, num_point, output + b0 * Lq * M * D,
         static_cast<hipStream_t>(stream), ref_points + b0 * ref_batch_stride, ref_batch_stride);
+    if (r != 0) return r == -100 ? PCT_ERR_UNSUPPORTED : r;
+  }
+  return PCT_OK;
+}
+
+int pct_ms_deform_attn_forward_planes_f32(const float *value_planes, const int64_t *spatial_shapes, const int64_t *level_start,
+                                          const float *loc_planes, const float *attn_planes, const float *ref_points,
+                                          long long ref_batch_stride, int batch, int spatial_size, int num_heads, int channels,
+                                          int num_levels, int num_query, int num_point, float *output, void *stream)
+{
+  const int rc = check_common(value_planes, spatial_shapes, level_start, loc_planes, attn_planes, batch, spatial_size, num_heads,
+                              channels, num_levels, num_query, num_point, 1, sizeof(float), sizeof(float));
+  if (rc != PCT_OK) return rc;
+  if (batch == 0 || num_query == 0) return PCT_OK;
+  if (!output || ref_batch_stride < 0) return PCT_ERR_BAD_ARG;
+  if (((uintptr_t)output | (uintptr_t)ref_points) & 3u) return PCT_ERR_ALIGNMENT;
+  if (num_query != spatial_size || channels != 16 || num_point != 4) return PCT_ERR_UNSUPPORTED;
+  const long long S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query, P = num_point;
+  const int chunk = images_per_launch(batch, S * M * D * 4);               // as forward_impl: < 2 GiB of value per launch
+  for (int b0 = 0; b0 < batch; b0 += chunk) {
+    const int n = batch - b0 < chunk ? batch - b0 : chunk;
+    const int r = pct::launch_msda_forward_planes(
+        value_planes + b0 * S * M * D, spatial_shapes, level_start, loc_planes + b0 * Lq * M * L * P * 2,
+        attn_planes + b0 * Lq * M * L * P, n, spatial_size, num_heads, channels, num_levels, num_query, num_point,
+        output + b0 * Lq * M * D, static_cast<hipStream_t>(stream), ref_points ? ref_points + b0 * ref_batch_stride : nullptr,
+        ref_batch_stride);
     if (r != 0) return r == -100 ? PCT_ERR_UNSUPPORTED : r;
   }
   return PCT_OK;

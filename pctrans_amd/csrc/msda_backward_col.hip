@@ -526,7 +526,7 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
   while (have) {
     asm volatile("" : "+v"(tid), "+v"(qi), "+v"(lane_slot), "+v"(lane_c0));
     unsigned rfetch = 0u;
-    if (queue && tid == 0) rfetch = atomicAdd(queue + xcd, 1u);
+    if (queue && tid == 0) rfetch = atomicAdd(queue + xcd * WIN_QUEUE_STRIDE, 1u);
     const unsigned own = rec_index(qv, m);                                    // this lane's record: query * M + head
     const bool idle = qv < 0;
 
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(BCOL_BLOCK, 2) void msda_backward_col_kernel(
     if (tid == 0) {
       unsigned fetched = (unsigned)(item - xcd * chunk + nslots);             // static stride when there is no queue
       if (queue) {
-        if (rfetch + 1u >= n_x) atomicExch(queue + xcd, 0u);                   // that was the launch's last fetch
+        if (rfetch + 1u >= n_x) atomicExch(queue + xcd * WIN_QUEUE_STRIDE, 0u);                   // that was the launch's last fetch
         fetched = (unsigned)nslots + rfetch;
       }
       next_idx[0] = fetched;

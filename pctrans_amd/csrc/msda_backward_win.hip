@@ -95,7 +95,7 @@ __global__ __launch_bounds__(WIN_BLOCK, 2) void msda_backward_win_kernel(
   int item = xcd * chunk + slot0;
   while (item < item_end) {
     unsigned rfetch = 0u;                                            // looked at right before barrier (1)
-    if (queue && tid == 0) rfetch = atomicAdd(queue + xcd, 1u);
+    if (queue && tid == 0) rfetch = atomicAdd(queue + xcd * WIN_QUEUE_STRIDE, 1u);
     const int m = item % M;
     const int bt = item / M;
     const int t = bt % T_img;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(WIN_BLOCK, 2) void msda_backward_win_kernel(
     if (tid == 0) {
       unsigned fetched = (unsigned)(item - xcd * chunk + nslots);   // static stride when there is no queue
       if (queue) {
-        if (rfetch + 1u >= (unsigned)(item_end - xcd * chunk)) atomicExch(queue + xcd, 0u);
+        if (rfetch + 1u >= (unsigned)(item_end - xcd * chunk)) atomicExch(queue + xcd * WIN_QUEUE_STRIDE, 0u);
         fetched = (unsigned)nslots + rfetch;
       }
       next_idx[0] = fetched;

@@ -201,7 +201,7 @@ int launch_msda_forward_dpp(const void *, const int64_t *, const int64_t *, cons
                             int, int, int, int, void *, hipStream_t, const float *, long long);   // msda_forward_dpp.hip
 
 int launch_msda_forward_col(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
-                            int, int, int, int, void *, hipStream_t, const float *, long long);   // msda_forward_col.hip
+                            int, int, int, int, void *, hipStream_t, const float *, long long, bool);   // msda_forward_col.hip
 template <typename T>
 int launch_msda_forward_col16(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int,
                               int, int, int, int, void *, hipStream_t, const float *, long long);  // msda_forward_col16.hip
@@ -255,7 +255,7 @@ int launch_msda_forward_special(const void *value, const int64_t *shapes, const 
   if constexpr (sizeof(typename Traits<T>::store_t) == 4) {
     const bool col_big = (long long)N * S * M >= (L >= 4 ? 160000LL : 450000LL);
     if (choice == 4 || (choice == 0 && Lq == S && P == 4 && col_big)) {
-      rc = launch_msda_forward_col(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream, ref, ref_batch_stride);
+      rc = launch_msda_forward_col(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream, ref, ref_batch_stride, false);
       if (rc != -100) note_msda_kernel(4);
     }
   }
@@ -280,6 +280,17 @@ int launch_msda_forward_special(const void *value, const int64_t *shapes, const 
   }
   return rc;
 }
+// piece-plane operands (pct_ms_deform_attn_forward_planes_f32): the pyramid-column kernel or nothing (-100)
+int launch_msda_forward_planes(const void *value, const int64_t *shapes, const int64_t *starts, const void *loc,
+                               const void *attn, int N, int S, int M, int D, int L, int Lq, int P, void *out,
+                               hipStream_t stream, const float *ref, long long ref_batch_stride)
+{
+  const int rc = launch_msda_forward_col(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out, stream, ref,
+                                         ref_batch_stride, true);
+  if (rc != -100) note_msda_kernel(4);
+  return rc;
+}
+
 template int launch_msda_forward_special<float>(const void *, const int64_t *, const int64_t *, const void *,
                                                 const void *, int, int, int, int, int, int, int, void *, hipStream_t,
                                                 const float *, long long);

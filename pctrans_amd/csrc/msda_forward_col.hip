@@ -84,6 +84,21 @@ namespace pct {
 #ifndef PCT_COL_KO_NOGATHER
 #define PCT_COL_KO_NOGATHER 0 /* knock-out (WRONG RESULTS, timing only): 1 = no LDS reads + FMAs in the gather, 2 = no gather at all */
 #endif
+#ifndef PCT_COL_LATIN
+#define PCT_COL_LATIN 2       /* LDS gather with a per-lane corner order that is bank-conflict free for ANY locations (see
+                                 gather_level_lds_latin): 0 = off, 1 = every level, 2 = levels whose window is much larger than the
+                                 column's cell (wide offset distributions).  Same-box A/B, P2 batch 128 (profiles/
+                                 r04_forward_structural_ab.txt): 2 against 0: M 2.168 -> 2.085 ms as an op, 2.290 -> 2.209 ms in the
+                                 bench step; I 1.649 -> 1.700 (the two code paths cost the init-like case 3 spilled registers); 1: M 2.038,
+                                 I 1.779 */
+#endif
+#ifndef PCT_COL_LATIN_HALO
+#define PCT_COL_LATIN_HALO 16
+#endif
+#ifndef PCT_COL_KO_ALIAS
+#define PCT_COL_KO_ALIAS 0    /* knock-out (WRONG RESULTS, timing only): every image reads and writes image 0's tensors -- the same instruction
+                                 stream with (almost) no HBM traffic: what the kernel costs when memory bandwidth is free */
+#endif
 #ifndef PCT_COL_KO_NOCONF
 #define PCT_COL_KO_NOCONF 0   /* knock-out (WRONG RESULTS, timing only): LDS gather addresses forced conflict-free */
 #endif
@@ -102,7 +117,7 @@ namespace pct {
 
 // The knock-out switches produce WRONG RESULTS by design (timing experiments, tools/variant.sh): a library built with one
 // of them must say so -- refused unless the build declares itself an experiment, and reported by pct_build_info().
-#if (PCT_COL_KO_NOLOC || PCT_COL_KO_NOSTORE || PCT_COL_KO_NOSTAGE || PCT_COL_KO_NOGATHER || PCT_COL_KO_NOCONF) && \
+#if (PCT_COL_KO_NOLOC || PCT_COL_KO_NOSTORE || PCT_COL_KO_NOSTAGE || PCT_COL_KO_NOGATHER || PCT_COL_KO_NOCONF || PCT_COL_KO_ALIAS) && \
     !defined(PCT_EXPERIMENT_BUILD)
 #error "PCT_COL_KO_* knock-outs give wrong results: add -DPCT_EXPERIMENT_BUILD (tools/variant.sh does) to build one"
 #endif
@@ -111,11 +126,11 @@ namespace pct {
 const char *msda_forward_col_build_flags()
 {
   return "col: KO=" PCT_STR(PCT_COL_KO_NOLOC) PCT_STR(PCT_COL_KO_NOSTORE) PCT_STR(PCT_COL_KO_NOSTAGE) PCT_STR(PCT_COL_KO_NOGATHER)
-         PCT_STR(PCT_COL_KO_NOCONF) " STORE_NT=" PCT_STR(PCT_COL_STORE_NT) " LOC_NT=" PCT_STR(PCT_COL_LOC_NT) " W_NT=" PCT_STR(PCT_COL_W_NT)
+         PCT_STR(PCT_COL_KO_NOCONF) PCT_STR(PCT_COL_KO_ALIAS) " STORE_NT=" PCT_STR(PCT_COL_STORE_NT) " LOC_NT=" PCT_STR(PCT_COL_LOC_NT) " W_NT=" PCT_STR(PCT_COL_W_NT)
          " STREAM_NT=" PCT_STR(PCT_COL_STREAM_NT) " W_LATE=" PCT_STR(PCT_COL_W_LATE) " ITEM_ORDER=" PCT_STR(PCT_COL_ITEM_ORDER)
          " EARLY=" PCT_STR(PCT_COL_EARLY) " EARLY_WAIT=" PCT_STR(PCT_COL_EARLY_WAIT) " PRIO=" PCT_STR(PCT_COL_PRIO) "/" PCT_STR(PCT_COL_PRIO_TOP)
          PCT_STR(PCT_COL_PRIO_PLAN) PCT_STR(PCT_COL_PRIO_L0) PCT_STR(PCT_COL_PRIO_REST) PCT_STR(PCT_COL_PRIO_FRONT) " ORDER=" PCT_STR(PCT_COL_ORDER)
-         " LOC_AT=" PCT_STR(PCT_COL_LOC_AT);
+         " LOC_AT=" PCT_STR(PCT_COL_LOC_AT) " LATIN=" PCT_STR(PCT_COL_LATIN) "/" PCT_STR(PCT_COL_LATIN_HALO);
 }
 
 // Gather order of the levels (step ll -> level).  The finest level (the last one in PCTrans' pyramids) comes first; its
@@ -129,7 +144,14 @@ __host__ __device__ constexpr int col_level_of_step(const int ll)
   return PCT_COL_ORDER == 0 ? L - 1 - ll : (ll == 0 ? L - 1 : (ll == 1 ? 0 : L - ll));
 }
 
-template <int L, bool FUSED, int BLOCK, bool STAMP = false>
+// PP ("piece planes", an MI355X-native operand layout for the callers that control the producers -- the encoder's own
+// projection GEMM writes it, pct_ms_deform_attn_forward_planes_f32): value, locations / offsets and weights / logits are
+// stored per image as [heads * pieces][queries][4 floats], piece = four consecutive floats of a (query, head) record.  A
+// lane then loads piece i of ITS OWN record at (plane * S + query) * 16: the 64 lanes of a wave read the pieces of
+// consecutive queries, i.e. whole 128-byte lines, 2 - 8 tag look-ups per instruction -- and the quad-cooperative access with
+// its register transposes (176 vector instructions per wave and item), the half lines a record shares with its sibling
+// head's and the 64-byte-in-512 pixel slices of the window staging are all gone.  Same arithmetic, bit-identical output.
+template <int L, bool FUSED, int BLOCK, bool STAMP = false, bool PP = false>
 __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) void msda_forward_col_kernel(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const float *__restrict__ loc, const float *__restrict__ attn, const int N, const int S, const int M,
@@ -303,6 +325,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
     // L2: measured 1.41x / 1.92x the algorithmic bytes on the memory side for distributions I / M.)
     b_ = udiv_s(it, dv_ncolM);
     const int r_img = it - b_ * (ncol * M);
+    if (PCT_COL_KO_ALIAS) b_ = 0;
     int col;
     if (PCT_COL_ITEM_ORDER == 1 && M == 8) {                                   // (experiment) column outermost, the 8 heads adjacent
       col = r_img >> 3;
@@ -375,6 +398,20 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
   auto issue_loc = [&](const int b_, const int m_, const int qv_, col_f32x4 (&raw)[NGL][4]) {
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(loc + (long long)b_ * S * M * (L * P * 2)), 0,
                                                       (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 8)), RSRC_FLAGS);
+    if constexpr (PP) {                           // piece i of (query, head m_): plane m_ * NPL + i, the plane in the scalar offset
+      const unsigned qo = (unsigned)(qv_ ^ (qv_ >> 31)) << 4;
+      const unsigned s16 = (unsigned)__builtin_amdgcn_readfirstlane(S) * 16u;
+      const unsigned p0 = (unsigned)__builtin_amdgcn_readfirstlane(m_) * (unsigned)NPL * s16;       // (scalar unit, not 12 vector multiplies)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int g = 0; g < NGL; ++g)
+          raw[g][s4] = g * 4 + s4 < NPL
+                           ? __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                 rs, (int)qo, (int)(p0 + (unsigned)(g * 4 + s4) * s16), PCT_COL_LOC_NT ? 2 : 0))
+                           : col_f32x4{0.f, 0.f, 0.f, 0.f};
+      return;
+    }
     unsigned off[4];
     quad_offsets(rec_index(qv_, m_) * (unsigned)(L * P * 8), off);
     if (PCT_COL_KO_NOLOC == 1 || PCT_COL_KO_NOLOC == 2) {
@@ -420,7 +457,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
   if (have) {
     decode(item, b, m, qv);
     issue_loc(b, m, qv, raw);
-    if (queue && tid == 0) next_idx[1] = atomicAdd(queue + xcd, 1u);
+    if (queue && tid == 0) next_idx[1] = atomicAdd(queue + xcd * WIN_QUEUE_STRIDE, 1u);
   }
 
   stamp(-1);
@@ -437,8 +474,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
     // ---- the record: sampling locations (FUSED: reference point + offset / (W, H)), loaded one item ago ----------------
     col_f32x2 lxy[L][P];
     {
+      if constexpr (!PP) {
 #pragma unroll
-      for (int g = 0; g < NGL; ++g) quad_transpose_in(raw[g], qi0, qi1);
+        for (int g = 0; g < NGL; ++g) quad_transpose_in(raw[g], qi0, qi1);
+      }
 #pragma unroll
       for (int l = 0; l < L; ++l)
 #pragma unroll
@@ -479,13 +518,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       if (queue) {
         const unsigned f_next = next_idx[1];
         if (f_next + 1u >= n_x)                                               // that was the launch's last fetch
-          __hip_atomic_store(queue + xcd, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(queue + xcd * WIN_QUEUE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         nxt = (unsigned)nslots + f_next;
         if (nxt < n_x) {
           // (inline asm: the compiler waits for a returning atomic at the end of this divergent block -- a full round
           // trip to L2 in front of the pre-pass; the wait now sits where the value is parked, behind the pre-pass)
           const unsigned one = 1u, zero = 0u;
-          const unsigned *qp = queue + xcd;
+          const unsigned *qp = queue + xcd * WIN_QUEUE_STRIDE;
           // (s_nop: the base may just have been restored by v_readlane; a vector-memory instruction reading a scalar
           // register a vector instruction wrote needs 5 wait states, and the hazard recogniser does not see into inline asm)
           asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0"
@@ -516,6 +555,20 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
     auto load_weights = [&]() {
       const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(attn + (long long)b * S * M * (L * P)), 0,
                                                         (int)((unsigned)S * (unsigned)M * (unsigned)(L * P * 4)), RSRC_FLAGS);
+      if constexpr (PP) {                         // piece = level: the level's P = 4 weights of (query, head)
+        const unsigned qo = (unsigned)(qv ^ (qv >> 31)) << 4;
+        const unsigned s16 = (unsigned)__builtin_amdgcn_readfirstlane(S) * 16u;
+        const unsigned p0 = (unsigned)__builtin_amdgcn_readfirstlane(m) * (unsigned)L * s16;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int g = 0; g < NGW; ++g)
+            wraw[g][s4] = g * 4 + s4 < L
+                              ? __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                    rs, (int)qo, (int)(p0 + (unsigned)(g * 4 + s4) * s16), PCT_COL_W_NT ? 2 : 0))
+                              : col_f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+      }
       unsigned off[4];
       quad_offsets(own * (unsigned)(L * P * 4), off);
 #pragma unroll
@@ -548,6 +601,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
 
     // ---- windows and phases (uniform) --------------------------------------------------------------------------------
     int wx0[L], wy0[L], wwid[L], whgt[L], wsize[L], wbase[L], phase_of[L];
+    bool latin[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) latin[l] = false;
     bool starts_phase[L];
     {
 #pragma unroll
@@ -560,6 +616,15 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
         wx0[l] = (int)lx - 2;
         wy0[l] = (int)ly - 2;
         wwid[l] = (int)((hi & 0xFFFFu) - lx) + 1;
+        // (conflict-free corner order, below: the four corners of a sample must fall into four different bank classes --
+        // pool index mod 4 -- which they do when the window is 2 mod 4 pixels wide; the extra columns are staged like any other)
+        // PCT_COL_LATIN == 2: only where the box is much larger than the column's cell on this level, i.e. where the lanes'
+        // offsets differ by several pixels and their pixel classes collide (model-like offsets: halo ~14 + 14 pixels; the
+        // init-like ones, whose classes are consecutive by construction, stay at 4 - 10 and keep the cheaper fixed order)
+        if (PCT_COL_LATIN == 1) latin[l] = true;
+        if (PCT_COL_LATIN == 2)
+          latin[l] = (wwid[l] - col_max_cell(Ws[l], CX)) + ((int)((hi >> 16) - ly) + 1 - col_max_cell(Hs[l], CY)) >= PCT_COL_LATIN_HALO;
+        if (latin[l]) wwid[l] += (2 - wwid[l]) & 3;
         whgt[l] = (int)((hi >> 16) - ly) + 1;
         wsize[l] = wwid[l] * whgt[l];
       }
@@ -706,6 +771,61 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
         }(), ...);
       }(std::make_integer_sequence<int, P>{});
     };
+    // The same level with a CONFLICT-FREE corner order.  The LDS serves a ds_read_b128 in groups of 16 lanes, four lanes of
+    // each 8-lane block (one QUAD) per group; the piece rotation above keeps the quads of a group on different bank
+    // quarters, so what is left to collide are the four lanes of a quad whose pixels fall into the same class (pool index
+    // mod 4: pixels are 64 B = 16 banks apart) -- with model-like offsets 59 % of all LDS cycles of the kernel.  A sample's
+    // four corners are the pool indices i, i + 1, i + width, i + width + 1: with the window width = 2 (mod 4) they are one
+    // pixel of EACH class.  So lane q of the quad starts with the corner of class q and walks the classes upwards: at every
+    // corner step the quad's four lanes read four different classes, whatever the locations.  Price: the corner order
+    // differs per lane and sample -- offsets and weights are selected by two bits of (q - i) -- ~27 vector instructions
+    // per sample more than the fixed order.  The sums are accumulated in a different order per lane than with the fixed
+    // order (results agree to rounding, not bit for bit).
+    auto gather_level_lds_latin = [&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+        ([&] {
+          asm volatile("" : "+v"(lxy[l][Ks]));
+          const col_f32x2 pix = lxy[l][Ks];
+          const int x0 = cvt_flr(pix[0]), y0 = cvt_flr(pix[1]);
+          const float lw = __builtin_amdgcn_fractf(pix[0]), lh = __builtin_amdgcn_fractf(pix[1]);
+          const float hw = 1.f - lw, hh = 1.f - lh;
+          const col_f32x2 tw = col_f32x2{hw, lw} * col_f32x2{wts[l][Ks], wts[l][Ks]};      // (hw, lw) * w, as the fixed order
+          const unsigned pi = (unsigned)(__mul24(y0, wwid[l]) + x0 + woff[l]);
+          const unsigned e = ((unsigned)qi - pi) & 3u;          // first corner d = dx + 2 dy of this lane; then d + 1, d + 2, d + 3 (mod 4)
+          const bool e0 = e & 1u, e1 = e & 2u, f1 = (e + 1u) & 2u;                          // dy of the steps: e1, f1, !e1, !f1
+          const float wa = e0 ? tw[1] : tw[0], wb = e0 ? tw[0] : tw[1];                    // dx of the steps: e0, !e0, e0, !e0
+          const unsigned rowb = (unsigned)wwid[l] << 6;
+          const unsigned base = pi << 6;
+          const unsigned xa = e0 ? 64u : 0u, xb = xa ^ 64u;
+          const unsigned a0 = base + xa + (e1 ? rowb : 0u), a1 = base + xb + (f1 ? rowb : 0u);
+          const unsigned a2 = base + xa + (e1 ? 0u : rowb), a3 = base + xb + (f1 ? 0u : rowb);
+          const float w0 = wa * (e1 ? lh : hh), w1 = wb * (f1 ? lh : hh), w2 = wa * (e1 ? hh : lh), w3 = wb * (f1 ? hh : lh);
+          {
+            col_f32x4 va[4], vb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              va[j] = *reinterpret_cast<const col_f32x4 *>(pool + (a0 + rot[j]));
+              vb[j] = *reinterpret_cast<const col_f32x4 *>(pool + (a1 + rot[j]));
+            }
+            fma_row(va, vb, w0, w1);
+          }
+          pin_acc();
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            col_f32x4 va[4], vb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              va[j] = *reinterpret_cast<const col_f32x4 *>(pool + (a2 + rot[j]));
+              vb[j] = *reinterpret_cast<const col_f32x4 *>(pool + (a3 + rot[j]));
+            }
+            fma_row(va, vb, w2, w3);
+          }
+          pin_acc();
+          __builtin_amdgcn_sched_barrier(0);
+        }(), ...);
+      }(std::make_integer_sequence<int, P>{});
+    };
     // ... or from global memory (a level whose box exceeds the pool), through the buffer descriptor: out-of-map corners
     // get an out-of-range offset and read zeros.  A head-pixel is 64 contiguous bytes; fetched lane by lane, every
     // 16-byte access of a wave instruction touches a different 128-byte line and the texture addresser serialises the 64
@@ -732,13 +852,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
           const Geo g = geometry(lc, std::integral_constant<int, Ks>{});
           const bool top = (unsigned)g.y0 < (unsigned)H, bot = (unsigned)(g.y0 + 1) < (unsigned)H;   // (y0, x0 in [-2, H] x [-2, W])
           const bool lft = (unsigned)g.x0 < (unsigned)W, rgt = (unsigned)(g.x0 + 1) < (unsigned)W;
-          const unsigned a = (unsigned)(St[l] + g.y0 * W + g.x0) * MDb + (unsigned)(m * D) * 4u;
-          const unsigned o1 = (top && lft) ? a : OOB, o2 = (top && rgt) ? a + MDb : OOB;
-          const unsigned o3 = (bot && lft) ? a + (unsigned)W * MDb : OOB, o4 = (bot && rgt) ? a + (unsigned)W * MDb + MDb : OOB;
+          // (PP: piece c of pixel p of head m at ((m * 4 + c) * S + p) * 16: the pixel stride is 16 bytes, the piece a plane)
+          const unsigned pxs = PP ? 16u : MDb;
+          const unsigned a = PP ? (unsigned)(m * (D / 4) * S + St[l] + g.y0 * W + g.x0) * 16u
+                                : (unsigned)(St[l] + g.y0 * W + g.x0) * MDb + (unsigned)(m * D) * 4u;
+          const unsigned o1 = (top && lft) ? a : OOB, o2 = (top && rgt) ? a + pxs : OOB;
+          const unsigned o3 = (bot && lft) ? a + (unsigned)W * pxs : OOB, o4 = (bot && rgt) ? a + (unsigned)W * pxs + pxs : OOB;
           [&]<int... Ss>(std::integer_sequence<int, Ss...>) {                    // one member at a time (16 registers of data)
             ([&] {
               constexpr int CT = BcastCtrl<4, Ss>::value;
-              const unsigned pc = (unsigned)((Ss - qi) & 3) << 4;              // (an out-of-range offset stays out of range)
+              const unsigned pc = PP ? (unsigned)((Ss - qi) & 3) * ((unsigned)S * 16u)     // (an out-of-range offset stays out of range)
+                                     : (unsigned)((Ss - qi) & 3) << 4;
               col_f32x4 v[4];
               v[0] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(dpp_u<CT>(o1) + pc), 0, 0));
               v[1] = __builtin_bit_cast(col_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(dpp_u<CT>(o2) + pc), 0, 0));
@@ -791,12 +915,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
 #pragma unroll
       for (int l = 0; l < L; ++l) {
         if (phase_of[l] == phx && wsize[l] > 0) {
-          const unsigned lvl_off = (unsigned)St[l] * MDb + (unsigned)(m * D) * 4u;   // bytes, this level and head
-          const unsigned row_bytes = (unsigned)Ws[l] * MDb;
+          // (PP: piece cc of a pixel lives in plane m * 4 + cc, pixels 16 bytes apart: a copy instruction reads four runs of
+          // 256 consecutive bytes instead of sixteen 64-byte slices 512 bytes apart)
+          const unsigned lvl_off = PP ? ((unsigned)(m * (D / 4)) * (unsigned)S + (unsigned)St[l]) * 16u
+                                      : (unsigned)St[l] * MDb + (unsigned)(m * D) * 4u;   // bytes, this level and head
+          const unsigned row_bytes = (unsigned)Ws[l] * (PP ? 16u : MDb);
           unsigned char *dst = pool + (size_t)wbase[l] * PXB;
           for (int c0 = 0; c0 < wwid[l]; c0 += CPX) {
             const int xw = c0 + dx, x = wx0[l] + xw;
-            const unsigned voff = (unsigned)x < (unsigned)Ws[l] ? (unsigned)x * MDb + (unsigned)(cc * 16) : OOB;
+            const unsigned voff = (unsigned)x < (unsigned)Ws[l]
+                                      ? (PP ? (unsigned)x * 16u + (unsigned)cc * ((unsigned)S * 16u) : (unsigned)x * MDb + (unsigned)(cc * 16))
+                                      : OOB;
             if (xw < wwid[l]) {
               for (int r = wv; r < whgt[l]; r += NW) {
                 const int y = wy0[l] + r;
@@ -812,8 +941,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       }
     };
     auto front_end = [&]() {                                                  // the weights, once they are needed
+      if constexpr (!PP) {
 #pragma unroll
-      for (int g = 0; g < NGW; ++g) quad_transpose_in(wraw[g], qi0, qi1);
+        for (int g = 0; g < NGW; ++g) quad_transpose_in(wraw[g], qi0, qi1);
+      }
 #pragma unroll
       for (int l = 0; l < L; ++l)
 #pragma unroll
@@ -896,7 +1027,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (BLOCK == 512 ? 4 : 3)) 
       if (PCT_COL_PRIO == 7) __builtin_amdgcn_s_setprio(ll == 0 ? 3 : 2);
       if (PCT_COL_PRIO == 8) __builtin_amdgcn_s_setprio(ll == 0 ? PCT_COL_PRIO_L0 : PCT_COL_PRIO_REST);
       if (PCT_COL_KO_NOGATHER == 2) {
-      } else if (phase_of[l] >= 0) gather_level_lds(std::integral_constant<int, l>{});
+      } else if (phase_of[l] >= 0) {
+        if constexpr (PCT_COL_LATIN == 1) gather_level_lds_latin(std::integral_constant<int, l>{});
+        else if constexpr (PCT_COL_LATIN == 2) {
+          if (latin[l]) gather_level_lds_latin(std::integral_constant<int, l>{});
+          else gather_level_lds(std::integral_constant<int, l>{});
+        } else
+          gather_level_lds(std::integral_constant<int, l>{});
+      }
       else gather_level_global(std::integral_constant<int, l>{});             // box larger than the pool: global memory
       // (marking the global-memory path unlikely makes hipcc outline it behind a real call: 544 bytes of scratch per lane, 10x slower)
       if (ll == 0) stamp(10);                                                 // first level gathered
@@ -978,7 +1116,7 @@ unsigned long long *win_stamp_buffer();                                      // 
 // ref == nullptr: plain op; ref != nullptr: fused front-end (loc = raw offsets, attn = raw logits).
 int launch_msda_forward_col(const void *value, const int64_t *shapes, const int64_t *starts, const void *loc,
                             const void *attn, int N, int S, int M, int D, int L, int Lq, int P, void *out,
-                            hipStream_t stream, const float *ref, long long ref_batch_stride)
+                            hipStream_t stream, const float *ref, long long ref_batch_stride, bool planes)
 {
   if ((((uintptr_t)value | (uintptr_t)out | (uintptr_t)loc | (uintptr_t)attn) & 15u)) return -100;
   if (ref && (((uintptr_t)ref) & ((L % 2 == 0) ? 15u : 7u))) return -100;
@@ -1023,6 +1161,27 @@ int launch_msda_forward_col(const void *value, const int64_t *shapes, const int6
     else PCT_COL_K(L_, FU_, 256, ST_);                         \
   } while (0)
 #define PCT_COL(L_, FU_) PCT_COL_B(L_, FU_, false)
+  if (planes) {                         // piece-plane operands (see the kernel): 256-thread workgroups only
+    if (BLOCKV != 256) return -100;
+#define PCT_COL_PP(L_, FU_)                                                                                             \
+  do {                                                                                                                  \
+    const hipError_t attr_rc = func_attr_per_device(reinterpret_cast<const void *>(&msda_forward_col_kernel<L_, FU_, 256, false, true>)); \
+    if (attr_rc != hipSuccess) return (int)attr_rc;                                                                     \
+    hipLaunchKernelGGL((msda_forward_col_kernel<L_, FU_, 256, false, true>), grid, block, lds, stream, v, shapes, starts, lc, \
+                       at, N, S, M, pool_px, o, ref, ref_batch_stride, queue, nullptr);                                 \
+  } while (0)
+    if (ref) {
+      if (L == 3) PCT_COL_PP(3, true);
+      else if (L == 4) PCT_COL_PP(4, true);
+      else PCT_COL_PP(5, true);
+    } else {
+      if (L == 3) PCT_COL_PP(3, false);
+      else if (L == 4) PCT_COL_PP(4, false);
+      else PCT_COL_PP(5, false);
+    }
+#undef PCT_COL_PP
+    return (int)hipGetLastError();
+  }
   if (win_stamp_buffer() && L == 4) {   // diagnostic: per-phase cycle stamps (tools/stamp_msda.py)
     if (ref) PCT_COL_B(4, true, true);
     else PCT_COL_B(4, false, true);

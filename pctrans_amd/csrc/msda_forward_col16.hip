@@ -232,7 +232,7 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
     [&]<int... Ls>(std::integer_sequence<int, Ls...>) {
       (issue_loc_level(std::integral_constant<int, Ls>{}, b, m, qv, raw), ...);
     }(std::make_integer_sequence<int, L>{});
-    if (queue && tid == 0) next_idx[1] = atomicAdd(queue + xcd, 1u);
+    if (queue && tid == 0) next_idx[1] = atomicAdd(queue + xcd * WIN_QUEUE_STRIDE, 1u);
   }
 
   while (have) {
@@ -273,11 +273,11 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
       unsigned nxt = (unsigned)(item - xcd * chunk + nslots);
       if (queue) {
         const unsigned f_next = next_idx[1];
-        if (f_next + 1u >= n_x) __hip_atomic_store(queue + xcd, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f_next + 1u >= n_x) __hip_atomic_store(queue + xcd * WIN_QUEUE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         nxt = (unsigned)nslots + f_next;
         if (nxt < n_x) {
           const unsigned one = 1u, zero = 0u;
-          const unsigned *qp = queue + xcd;
+          const unsigned *qp = queue + xcd * WIN_QUEUE_STRIDE;
           asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0"
                        : "=v"(f_new) : "v"(zero), "v"(one), "s"(qp) : "memory");
           fetched = true;

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
     stamp(1);
     // (the counter's answer is first looked at right before barrier (2): the round trip hides behind the staging)
     unsigned rfetch = 0u;
-    if (queue && tid == 0) rfetch = atomicAdd(queue + xcd, 1u);
+    if (queue && tid == 0) rfetch = atomicAdd(queue + xcd * WIN_QUEUE_STRIDE, 1u);
 
     // ---- windows (identical in every lane; kept in SGPRs) -------------------------------------------------------
     int wx0[L], wy0[L], wwid[L], wbase[L], wsize[L], in_lds[L];
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(WIN_BLOCK, (NS == 4 || P == 8) ? 3 : 4) void msda_f
     if (tid == 0) {
       unsigned fetched = (unsigned)(item - xcd * chunk + nslots);   // static stride when there is no queue
       if (queue) {
-        if (rfetch + 1u >= (unsigned)(item_end - xcd * chunk)) atomicExch(queue + xcd, 0u);
+        if (rfetch + 1u >= (unsigned)(item_end - xcd * chunk)) atomicExch(queue + xcd * WIN_QUEUE_STRIDE, 0u);
         fetched = (unsigned)nslots + rfetch;
       }
       next_idx[0] = fetched;
@@ -568,7 +568,7 @@ unsigned *win_queue_slot(hipStream_t stream)
     // never allocate under stream capture (an allocation would invalidate the capture): static stride for this launch
     if (capturing) return nullptr;
     void *p = nullptr;
-    const size_t bytes = (size_t)(RING + CAPTURE_POOL) * 8 * sizeof(unsigned);
+    const size_t bytes = (size_t)(RING + CAPTURE_POOL) * 8 * WIN_QUEUE_STRIDE * sizeof(unsigned);
     // (the memset runs on the null stream; launches may come from non-blocking streams: wait for it once)
     if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
       (void)hipGetLastError();
@@ -579,9 +579,9 @@ unsigned *win_queue_slot(hipStream_t stream)
   }
   if (capturing) {
     if (cap_used[dev] >= (unsigned)CAPTURE_POOL) return nullptr;
-    return ring[dev] + 8 * (size_t)(RING + cap_used[dev]++);
+    return ring[dev] + 8 * WIN_QUEUE_STRIDE * (size_t)(RING + cap_used[dev]++);
   }
-  return ring[dev] + 8 * (seq[dev]++ % RING);
+  return ring[dev] + (size_t)8 * WIN_QUEUE_STRIDE * (seq[dev]++ % RING);
 }
 
 int prepare_win_queue_device()

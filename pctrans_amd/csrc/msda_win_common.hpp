@@ -107,6 +107,17 @@ inline hipError_t func_attr_per_device(const void *fn)
 // msda_forward_win.hip; nullptr = use the static item stride).  Protocol inside the kernels: the first round of items is
 // static (workgroup slot), every further item of XCD x is nslots + atomicAdd(queue + x, 1); every processed item costs
 // exactly one fetch, so the fetch that returns n_x - 1 is the launch's last one and zeroes the counter again.
+// The 8 counters of a set are WIN_QUEUE_STRIDE unsigned apart (counter of XCD x: queue + x * WIN_QUEUE_STRIDE): 256 bytes, each
+// on a memory line of its own.  Packed into one 32-byte run (rounds 1-3) the eight counters shared a line, their returning
+// atomics were served one after the other wherever that line lives, and the whole chip could draw at most ~85 items per
+// microsecond: a launch with every memory operation, staging and gather knocked out took 1.03 ms for the north-star's
+// 87 040 items whether 1, 2 or 3 workgroups per CU ran it -- the figure rounds 2 and 3 read as "the record stream's
+// skeleton" -- and 0.34 ms with the counters apart (profiles/r04_forward_structural_ab.txt).  The product kernels draw
+// ~40 items per microsecond and hide the fetch two items ahead, so they did not get faster; the cap is gone.
+#ifndef PCT_QUEUE_STRIDE
+#define PCT_QUEUE_STRIDE 64
+#endif
+constexpr int WIN_QUEUE_STRIDE = PCT_QUEUE_STRIDE;
 unsigned *win_queue_slot(hipStream_t stream);
 int prepare_win_queue_device();     // allocate the ring now (outside any capture)
 
