@@ -83,7 +83,7 @@ __device__ __forceinline__ unsigned wave_reduce_umax(unsigned v)
 // hipFuncAttributeMaxDynamicSharedMemorySize = 160 KB for a kernel, once per (kernel, device): a function-local
 // `static const hipError_t rc = hipFuncSetAttribute(...)` ran once per PROCESS, i.e. only for the device that happened to be
 // current at the first launch (fine for one process per GPU, wrong for a process that drives several).
-inline hipError_t func_attr_per_device(const void *fn)
+inline hipError_t func_attr_per_device(const void *fn, const int bytes = 160 * 1024)   // (bytes: dynamic LDS only; static LDS counts against the 160 KB too)
 {
   constexpr int MAXD = 64, MAXF = 64;
   static std::mutex mu;
@@ -98,7 +98,7 @@ inline hipError_t func_attr_per_device(const void *fn)
     if (!fns[i]) { fns[i] = fn; slot = i; break; }
   }
   if (slot >= 0 && (done[slot] >> dev) & 1ull) return hipSuccess;
-  const hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (rc == hipSuccess && slot >= 0) done[slot] |= 1ull << dev;
   return rc;
 }
