@@ -267,6 +267,17 @@ PCT_API int pct_linear_add_layernorm_f32(const float *x, long long ldx, int k, c
                                          const float *beta, float eps, long long rows, float *out, long long ldo,
                                          void *stream);
 
+/* ---- 1x1 convolution on NCHW maps, fp32-accurate on the bf16 matrix cores (csrc/conv1x1_split.hip) -------------------
+ * Replaces the `Conv2d(in_channels, conv_dim, kernel_size=1)` of the pixel decoder's input projections and FPN laterals
+ * (pixel_decoder/msdeformattn.py:213-226, :262-277) for contiguous fp32 maps:
+ *     out[n][co][p] = bias[co] + sum_ci w[co][ci] * x[n][ci][p]
+ *   x [batch, in_channels, hw]  w [out_channels, in_channels]  bias [out_channels] or NULL  out [batch, out_channels, hw]
+ *   w_split_ws: device workspace of 3 * out_channels * in_channels * 2 bytes, refilled on every call (one per stream)
+ * Supported: out_channels == 128, in_channels % 16 == 0, hw % 128 == 0, 16-byte aligned tensors; otherwise
+ * PCT_ERR_UNSUPPORTED / PCT_ERR_ALIGNMENT and the caller keeps the library convolution.  Two launches on `stream`. */
+PCT_API int pct_conv1x1_nchw_f32(const float *x, const float *w, const float *bias, void *w_split_ws, int batch,
+                                 int in_channels, int out_channels, int hw, float *out, void *stream);
+
 /* ---- linear sum assignment on the device ------------------------------------------------------------------------
  * Replaces scipy.optimize.linear_sum_assignment(C.cpu()) of the matcher (connectomics/model/loss/matcher.py:154-165):
  * for every problem b, cost[b] is [num_query, ld_target] fp32 (row = query / prediction, column = target) of which the

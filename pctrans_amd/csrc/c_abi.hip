@@ -44,6 +44,7 @@ const char *msda_forward_col_build_flags();
 const char *msda_backward_col_build_flags();
 int launch_msda_forward_planes(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int, int,
                                int, int, int, void *, hipStream_t, const float *, long long);
+int launch_conv1x1_nchw_split(const float *, const float *, const float *, unsigned short *, int, int, int, float *, hipStream_t);
 int launch_cross_attention(const void *, const void *, const void *, const void *, const void *, const unsigned char *,
                            const unsigned char *, int, int, int, int, float, void *, hipStream_t);
 int launch_masked_attention(const void *, const void *, const void *, const unsigned char *, int, int, int, int, int,
@@ -413,6 +414,19 @@ int pct_groupnorm_flatten_f32(const float *x, const float *gamma, const float *b
   if ((uintptr_t)x & 15u) return PCT_ERR_ALIGNMENT;
   return pct::launch_groupnorm_flatten(x, gamma, beta, batch, channels, hw, groups, eps, stats, out, out_batch_stride,
                                        out_offset, static_cast<hipStream_t>(stream));
+}
+
+int pct_conv1x1_nchw_f32(const float *x, const float *w, const float *bias, void *w_split_ws, int batch, int in_channels,
+                         int out_channels, int hw, float *out, void *stream)
+{
+  if (batch < 0 || in_channels <= 0 || out_channels <= 0 || hw < 0) return PCT_ERR_BAD_ARG;
+  if (batch == 0 || hw == 0) return PCT_OK;
+  if (!x || !w || !w_split_ws || !out) return PCT_ERR_BAD_ARG;
+  if (out_channels != 128) return PCT_ERR_UNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)w_split_ws | (uintptr_t)out | (uintptr_t)bias) & 15u) return PCT_ERR_ALIGNMENT;
+  const int rc = pct::launch_conv1x1_nchw_split(x, w, bias, static_cast<unsigned short *>(w_split_ws), batch, in_channels, hw, out,
+                                                static_cast<hipStream_t>(stream));
+  return rc == -4 ? PCT_ERR_UNSUPPORTED : rc;
 }
 
 int pct_lsap_f32(const float *cost, int batch, int num_query, int ld_target, const int *num_target, int *row_for_target,

@@ -247,6 +247,44 @@ def linear_layer_norm(x, linear, residual, norm):
     return out.view(residual.shape)
 
 
+_CONV_WS = {}                 # (device, stream, in_channels) -> split-weight workspace of conv1x1_nchw (refilled per call)
+
+
+def conv1x1_nchw_supported(x, conv):
+    """fp32 contiguous NCHW device map through a plain 1x1 Conv2d with 128 output channels, forward only
+    (csrc/conv1x1_split.hip: in_channels % 16 == 0, H * W % 128 == 0)."""
+    w = conv.weight
+    return (isinstance(conv, torch.nn.Conv2d) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and w.dtype == torch.float32 and w.device == x.device and tuple(w.shape[2:]) == (1, 1) and w.shape[0] == 128
+            and w.shape[1] == x.shape[1] and w.shape[1] % 16 == 0 and (x.shape[2] * x.shape[3]) % 128 == 0
+            and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (0, 0) and tuple(conv.dilation) == (1, 1)
+            and conv.groups == 1 and getattr(conv, "norm", None) is None and getattr(conv, "activation", None) is None
+            and x.numel() > 0 and x.shape[0] * (x.shape[2] * x.shape[3] // 128) < 2 ** 31 - 1
+            and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and w.is_contiguous()
+            and (conv.bias is None or conv.bias.data_ptr() % 16 == 0) and not torch.is_autocast_enabled()
+            and not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)))
+
+
+def conv1x1_nchw(x, conv):
+    """conv(x) for a 1x1 Conv2d(in -> 128) on a contiguous fp32 NCHW map: exact split-bf16 products on the matrix cores
+    (as accurate as the fp32 convolution it replaces).  Falls back to the module where the kernel does not apply."""
+    if not conv1x1_nchw_supported(x, conv):
+        return conv(x)
+    n, k, h, w_ = x.shape
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    key = (x.device, stream, k)
+    ws = _CONV_WS.get(key)
+    if ws is None:
+        ws = _CONV_WS[key] = torch.empty((3, 128, k), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((n, 128, h, w_), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timing.timed("conv1x1 k=%d" % k, x):
+        rc = _lib.lib().pct_conv1x1_nchw_f32(
+            x.data_ptr(), conv.weight.data_ptr(), conv.bias.data_ptr() if conv.bias is not None else None, ws.data_ptr(),
+            n, k, 128, h * w_, out.data_ptr(), stream)
+    _lib.check(rc, "conv1x1_nchw")
+    return out
+
+
 def groupnorm_flatten_supported(x, gn):
     """fp32 NCHW device tensor, 128 channels, groups of a multiple of 4 channels, affine, forward only."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 128 and x.is_contiguous()

@@ -262,7 +262,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         with torch.autocast(device_type=dev_type, enabled=False):
             srcs, pos = [], []
             xs = [features[f].float() for f in self.transformer_in_features[::-1]]
-            convs = [self.input_proj[idx][0](x) for idx, x in enumerate(xs)]
+            convs = [fused_ops.conv1x1_nchw(x, self.input_proj[idx][0]) for idx, x in enumerate(xs)]
             src_flatten = None
             if all(fused_ops.groupnorm_flatten_supported(c, self.input_proj[idx][1]) for idx, c in enumerate(convs)):
                 # GroupNorm + flatten(2).transpose(1, 2) + the concat over the levels in one pass per level

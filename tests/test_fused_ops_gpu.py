@@ -585,3 +585,38 @@ def test_token_row_conv_never_serves_another_modules_weights():
     bias = conv.bias.view(1, -1, 1, 1)
     assert float(((b - bias) - 2.0 * (a - bias)).abs().max()) < 1e-4
     assert float((c - a).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("N,K,H,W,bias", [(2, 256, 128, 128, True), (3, 512, 68, 64, True), (1, 2048, 16, 16, True),
+                                          (2, 32, 8, 16, False), (5, 1024, 32, 32, True), (1, 16, 16, 8, True)])
+def test_conv1x1_nchw_is_as_accurate_as_fp32(N, K, H, W, bias):
+    """The pixel decoder's 1x1 input projections on the split-bf16 MFMA kernel (csrc/conv1x1_split.hip) against fp64:
+    error no larger than the fp32 convolution's own (pixel_decoder/msdeformattn.py:213-226)."""
+    from pctrans_amd.layers import Conv2d
+    torch.manual_seed(K + H)
+    conv = Conv2d(K, 128, kernel_size=1, bias=bias).cuda()
+    with torch.no_grad():
+        conv.weight.mul_(3.0)
+    x = torch.randn(N, K, H, W, device="cuda") * torch.logspace(-2, 2, K, device="cuda").view(1, K, 1, 1)
+    with torch.no_grad():
+        assert fused_ops.conv1x1_nchw_supported(x, conv)
+        got = fused_ops.conv1x1_nchw(x, conv)
+        ref64 = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double() if bias else None)
+        ref32 = conv(x)
+    scale = float(ref64.abs().max())
+    err = float((got.double() - ref64).abs().max()) / scale
+    err32 = float((ref32.double() - ref64).abs().max()) / scale
+    assert got.shape == ref32.shape and torch.isfinite(got).all()
+    assert err <= max(2.0 * err32, 2e-7), (err, err32)
+
+
+def test_conv1x1_nchw_falls_back_where_the_kernel_does_not_apply():
+    from pctrans_amd.layers import Conv2d
+    conv = Conv2d(64, 128, kernel_size=1).cuda()
+    x = torch.randn(1, 64, 10, 10, device="cuda")                    # 100 pixels: not a multiple of 128
+    assert not fused_ops.conv1x1_nchw_supported(x, conv)
+    with torch.no_grad():
+        assert torch.equal(fused_ops.conv1x1_nchw(x, conv), conv(x))
+    conv3 = Conv2d(64, 128, kernel_size=3, padding=1).cuda()
+    assert not fused_ops.conv1x1_nchw_supported(torch.randn(1, 64, 16, 8, device="cuda"), conv3)
+    assert not fused_ops.conv1x1_nchw_supported(torch.randn(1, 64, 16, 8, device="cuda").requires_grad_(), conv)
