@@ -277,7 +277,9 @@ def traffic_from_profile(args):
     `rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum` and `--pmc TCC_EA0_WRREQ_*` in separate passes around this very
     script, tools/pmc_bench_traffic.sh; bench.py cannot read counters itself).  Only reported when the committed
     measurement is for this workload."""
-    path = os.path.join(ROOT, "profiles", "r03_msda_traffic_batch%d_dist%s.json" % (args.batch, args.loc_dist))
+    path = os.path.join(ROOT, "profiles", "r04_msda_traffic_batch%d_dist%s.json" % (args.batch, args.loc_dist))
+    if not os.path.exists(path):          # (an older record of the same kernel family: still per launch of this workload)
+        path = os.path.join(ROOT, "profiles", "r03_msda_traffic_batch%d_dist%s.json" % (args.batch, args.loc_dist))
     try:
         with open(path) as f:
             t = json.load(f)

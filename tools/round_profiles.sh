@@ -1,7 +1,7 @@
 # End-of-round records (run on the GPU box from the repo root: tools/round_profiles.sh); copy what matters to profiles/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-T=${T:-r03}
+T=${T:-r04}
 python3 $R/bench.py > $R/gpurun_out/${T}_bench_distM.json 2> $R/gpurun_out/${T}_bench_distM.err || echo bench failed
 python3 $R/bench.py --loc-dist I --no-cpu-baseline > $R/gpurun_out/${T}_bench_distI.json 2> $R/gpurun_out/${T}_bench_distI.err || echo benchI failed
 rm -rf $R/gpurun_out/stats_b
