@@ -30,6 +30,12 @@
 #ifndef PCT_LIN_PRIO
 #define PCT_LIN_PRIO 0
 #endif
+#ifndef PCT_LIN_INTERLEAVE
+#define PCT_LIN_INTERLEAVE 1        /* 16 x 16 form: the next tile's split / LDS stores between the MFMAs (linear1 4.17 -> 3.95 ms, same-box A/B) */
+#endif
+#ifndef PCT_LIN_STAGGER
+#define PCT_LIN_STAGGER 0
+#endif
 
 namespace pct {
 
@@ -114,6 +120,17 @@ __global__ __launch_bounds__(SPL_BLOCK, 2) void linear_k128_split_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // provably wave-uniform (descriptor selects below)
+#if PCT_LIN_STAGGER
+  // Two workgroups share a CU (and every SIMD's matrix pipe).  Left alone they fall into lockstep -- both in their MFMA block at
+  // half rate each, then both splitting / staging with the matrix pipe idle.  A STATIC priority for the second half of the grid
+  // (the workgroups dispatched onto already occupied CUs) lets that workgroup's MFMAs go first whenever both want the pipe, so the
+  // pair settles into opposite phases: one multiplies while the other stages.
+#ifndef PCT_LIN_STAGGER_BY
+#define PCT_LIN_STAGGER_BY 0                                       /* 0: second half of the grid; 1: every second workgroup of an XCD */
+#endif
+  if (PCT_LIN_STAGGER_BY == 0 ? blockIdx.x >= (gridDim.x >> 1) : ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_setprio(PCT_LIN_STAGGER);
+#endif
+
   const int r = lane & 31, h = lane >> 5;
   // 1-D grid of nslots x nslices workgroups (nslots a multiple of 8).  Hardware deals workgroup g to XCD g % 8: the
   // nslices column slices of one tile slot are given ids that differ by multiples of 8, so they run on the same XCD
@@ -221,21 +238,22 @@ __global__ __launch_bounds__(SPL_BLOCK, 2) void linear_k128_split_kernel(
       }
     }
   };
+  auto stash_q = [&](unsigned char *dst, const int q, const spl_i32x4 (&g)[4], const spl_i32x4 (&g2)[4]) {
+    spl_f32x4 v = __builtin_bit_cast(spl_f32x4, g[q]);
+    if constexpr (HAS_X2) {
+      if (add_x2) v += __builtin_bit_cast(spl_f32x4, g2[q]);
+    }
+    unsigned a0, b0, c0, a1, b1, c1;
+    spl_split(v[0], v[1], a0, b0, c0);
+    spl_split(v[2], v[3], a1, b1, c1);
+    unsigned char *p = dst + s_off + q * 8 * SPL_ROWB;
+    *reinterpret_cast<uint2 *>(p) = make_uint2(a0, a1);
+    *reinterpret_cast<uint2 *>(p + SPL_PLANE) = make_uint2(b0, b1);
+    *reinterpret_cast<uint2 *>(p + 2 * SPL_PLANE) = make_uint2(c0, c1);
+  };
   auto stash = [&](unsigned char *dst, const spl_i32x4 (&g)[4], const spl_i32x4 (&g2)[4]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      spl_f32x4 v = __builtin_bit_cast(spl_f32x4, g[q]);
-      if constexpr (HAS_X2) {
-        if (add_x2) v += __builtin_bit_cast(spl_f32x4, g2[q]);
-      }
-      unsigned a0, b0, c0, a1, b1, c1;
-      spl_split(v[0], v[1], a0, b0, c0);
-      spl_split(v[2], v[3], a1, b1, c1);
-      unsigned char *p = dst + s_off + q * 8 * SPL_ROWB;
-      *reinterpret_cast<uint2 *>(p) = make_uint2(a0, a1);
-      *reinterpret_cast<uint2 *>(p + SPL_PLANE) = make_uint2(b0, b1);
-      *reinterpret_cast<uint2 *>(p + 2 * SPL_PLANE) = make_uint2(c0, c1);
-    }
+    for (int q = 0; q < 4; ++q) stash_q(dst, q, g, g2);
   };
 
   // stores: lane -> row lane/8 (+8i), 16 B at column 4*(lane%8): a wave instruction writes 8 full 128-B lines
@@ -297,6 +315,12 @@ __global__ __launch_bounds__(SPL_BLOCK, 2) void linear_k128_split_kernel(
             }
           }
           __builtin_amdgcn_sched_barrier(0);
+#if PCT_LIN_INTERLEAVE
+          // the NEXT tile's x, quarter sk: split into bf16 planes and stored into the other LDS image BETWEEN this step's MFMAs
+          // (an MFMA holds the SIMD's vector issue for 8 of its 16 cycles: one vector instruction per MFMA rides along) instead
+          // of in a block of ~100 vector instructions behind the last MFMA with the matrix pipe idle
+          stash_q(abuf[buf ^ 1], sk, gn, g2);
+#endif
 #pragma unroll
           for (int cw = 0; cw < 2; ++cw) {
             const spl_bf16x8 b1 = __builtin_bit_cast(spl_bf16x8, w1[4 * cw + sk]);
@@ -312,9 +336,18 @@ __global__ __launch_bounds__(SPL_BLOCK, 2) void linear_k128_split_kernel(
               alo[cw][rx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, x1[rx], alo[cw][rx], 0, 0, 0);
             }
           }
+#if PCT_LIN_INTERLEAVE
+#pragma unroll
+          for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      // one vector instruction
+          }
+#endif
         }
       }
+#if !PCT_LIN_INTERLEAVE
       stash(abuf[buf ^ 1], gn, g2);
+#endif
       {
         const auto ry = tile_rsrc(Y, ldy, active ? tile : ntiles);
         float *sw = oscr[wave];

@@ -22,6 +22,15 @@
 #ifndef PCT_LIN_PRIO
 #define PCT_LIN_PRIO 0
 #endif
+#ifndef PCT_LIN_STAGGER
+#define PCT_LIN_STAGGER 1          /* static priority for the second half of the grid: 4.605 -> 4.53 ms at 2.8 M rows (same-box A/B) */
+#endif
+#ifndef PCT_LLS_KO_ALIAS
+#define PCT_LLS_KO_ALIAS 0    /* knock-out (WRONG RESULTS, timing only): x and residual rows of every tile read from the first tiles (L2-resident) */
+#endif
+#if PCT_LLS_KO_ALIAS && !defined(PCT_EXPERIMENT_BUILD)
+#error "PCT_LLS_KO_ALIAS gives wrong results: add -DPCT_EXPERIMENT_BUILD"
+#endif
 
 namespace pct {
 
@@ -74,7 +83,18 @@ __global__ __launch_bounds__(LLS_BLOCK, 2) void linear_ln_split_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;                  // row half / column half of the 128 x 128 tile
+  const int wr = wave >> 1, wc = wave & 1;
+#if PCT_LIN_STAGGER
+  // Two workgroups share a CU (and every SIMD's matrix pipe).  Left alone they fall into lockstep -- both in their MFMA block at
+  // half rate each, then both splitting / staging with the matrix pipe idle.  A STATIC priority for the second half of the grid
+  // (the workgroups dispatched onto already occupied CUs) lets that workgroup's MFMAs go first whenever both want the pipe, so the
+  // pair settles into opposite phases: one multiplies while the other stages.
+#ifndef PCT_LIN_STAGGER_BY
+#define PCT_LIN_STAGGER_BY 0                                       /* 0: second half of the grid; 1: every second workgroup of an XCD */
+#endif
+  if (PCT_LIN_STAGGER_BY == 0 ? blockIdx.x >= (gridDim.x >> 1) : ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_setprio(PCT_LIN_STAGGER);
+#endif
+                  // row half / column half of the 128 x 128 tile
   const int r = lane & 31, h = lane >> 5;
 
   if (tid < 128) {
@@ -105,7 +125,7 @@ __global__ __launch_bounds__(LLS_BLOCK, 2) void linear_ln_split_kernel(
 
   lls_i32x4 gx[4], gw[6];
   auto fetch = [&](const long long tile, const int step) {
-    const auto rs = tile_rsrc(X, ldx, tile);
+    const auto rs = tile_rsrc(X, ldx, PCT_LLS_KO_ALIAS ? tile % 64 : tile);
 #pragma unroll
     for (int q = 0; q < 4; ++q) gx[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, xg_voff, step * (LLS_BK * 4) + 16 * q, 0);
 #pragma unroll
