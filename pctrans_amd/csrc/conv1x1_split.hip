@@ -2,8 +2,8 @@
 //     y[n][co][p] = b[co] + sum_ci W[co][ci] * x[n][ci][p],      co = 128, ci % 16 == 0, p = H * W % 128 == 0
 // (pixel_decoder/msdeformattn.py:213-226: `Conv2d(in_channels, conv_dim, kernel_size=1)` in front of GroupNorm(32, conv_dim),
 // applied to res2 .. res5; with four encoder levels the res2 projection -- 256 -> 128 channels on 128 x 128 maps -- is a
-// [2.1 M pixels x 256] x [256 x 128] product per step at batch 128).  MIOpen ran it as a CK grouped-convolution kernel on
-// the fp32 matrix path: 5.8 ms, 24 TFLOP/s, 9x its memory floor (3.2 GB), 7 % of the bench step.
+// [2.1 M pixels x 256] x [256 x 128] product per step at batch 128).  As a strided-batched fp32 GEMM through the BLAS library
+// (layers.Conv2d) the four levels took 2.78 ms per step at ~2 TB/s; here 1.76 ms at 2.3 - 3.3 TB/s (tools/bench_conv1x1.py).
 //
 // Same arithmetic as linear_k128_split.hip: every fp32 number is exactly the sum of three bf16 numbers, a product is
 // evaluated from its six leading bf16 x bf16 terms (a1w1 | a1w2 + a2w1 | a2w2 + a1w3 + a3w1) accumulated in fp32 by
