@@ -33,6 +33,9 @@
 #ifndef PCT_LIN_INTERLEAVE
 #define PCT_LIN_INTERLEAVE 1        /* 16 x 16 form: the next tile's split / LDS stores between the MFMAs (linear1 4.17 -> 3.95 ms, same-box A/B) */
 #endif
+#ifndef PCT_LIN_IL_DELAY
+#define PCT_LIN_IL_DELAY 1          /* merged projections 1.117 -> 1.102 ms (same-box A/B) */
+#endif
 #ifndef PCT_LIN_STAGGER
 #define PCT_LIN_STAGGER 0
 #endif
@@ -319,7 +322,9 @@ __global__ __launch_bounds__(SPL_BLOCK, 2) void linear_k128_split_kernel(
           // the NEXT tile's x, quarter sk: split into bf16 planes and stored into the other LDS image BETWEEN this step's MFMAs
           // (an MFMA holds the SIMD's vector issue for 8 of its 16 cycles: one vector instruction per MFMA rides along) instead
           // of in a block of ~100 vector instructions behind the last MFMA with the matrix pipe idle
-          stash_q(abuf[buf ^ 1], sk, gn, g2);
+          // (with a second operand x2 -- fetched for the next tile at the top of THIS tile, from L2 -- the first quarters wait
+          // PCT_LIN_IL_DELAY steps for it and the last ones follow the loop)
+          if (sk >= (HAS_X2 ? PCT_LIN_IL_DELAY : 0)) stash_q(abuf[buf ^ 1], sk - (HAS_X2 ? PCT_LIN_IL_DELAY : 0), gn, g2);
 #endif
 #pragma unroll
           for (int cw = 0; cw < 2; ++cw) {
@@ -347,6 +352,9 @@ __global__ __launch_bounds__(SPL_BLOCK, 2) void linear_k128_split_kernel(
       }
 #if !PCT_LIN_INTERLEAVE
       stash(abuf[buf ^ 1], gn, g2);
+#else
+#pragma unroll
+      for (int q = 4 - (HAS_X2 ? PCT_LIN_IL_DELAY : 0); q < 4; ++q) stash_q(abuf[buf ^ 1], q, gn, g2);
 #endif
       {
         const auto ry = tile_rsrc(Y, ldy, active ? tile : ntiles);
