@@ -371,6 +371,13 @@ def main():
     # at most 8 (40 untimed steps, ~4 s).  With several ranks the count is FIXED (4 blocks): a data-dependent exit would let
     # ranks enter the timed region after different numbers of steps.  Blocks taken and their per-step times go into the JSON
     # line (settle_steps / settle_ms); no collective inside.
+    # (Python's cyclic garbage collector stays off from here to the end of the timed region: a generation-2 pass over the module
+    # trees pauses the launching thread for 100-200 ms -- a step of 289 ms among steps of 101.7 in round 4 -- and with the host
+    # only ~30 % ahead of the device that is a hole in the stream.  Collected once here; reference counting still frees the
+    # step's tensors.)
+    import gc
+    gc.collect()
+    gc.disable()
     SETTLE_BLOCK = 5
     prev = None
     settle_ms = []
@@ -404,6 +411,7 @@ def main():
         step_marks[i_step + 1].record()       # one event per step: a straggler step shows in the JSON (step_ms)
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     step_ms = [step_marks[i].elapsed_time(step_marks[i + 1]) for i in range(args.steps)]
     launches = MSDA.kernel_timing(False)
 

@@ -267,6 +267,22 @@ PCT_API int pct_linear_add_layernorm_f32(const float *x, long long ldx, int k, c
                                          const float *beta, float eps, long long rows, float *out, long long ldo,
                                          void *stream);
 
+/* ---- input projection of the pixel decoder in one entry: 1x1 convolution + GroupNorm(32, 128) + flatten into token rows ----
+ * Replaces `nn.Sequential(Conv2d(in_channels, 128, kernel_size=1), nn.GroupNorm(32, 128))` followed by
+ * `.flatten(2).transpose(1, 2)` and the concat over the levels (pixel_decoder/msdeformattn.py:213-226, 75-83):
+ *     out[n][out_offset / 128 + p][c] = GroupNorm(conv(x))[n][c][p]
+ *   x [batch, in_channels, hw] fp32, w [128, in_channels], bias [128] or NULL, gamma / beta [128]
+ *   out: the [batch, S, 128] token buffer; out_batch_stride = S * 128 floats, out_offset = first row of this level * 128
+ *   w_split_ws: 3 * 128 * in_channels * 2 bytes; partial_ws: batch * (hw / 128) * 2 * 64 floats; stats: batch * 64 floats
+ * The convolution writes the token rows directly (its lanes hold 4 consecutive channels of a pixel) together with per-tile
+ * (mean, centred sum of squares) records per group; the statistics are combined with Chan's formula and the rows normalised in
+ * place.  Supported: out_channels == 128, groups == 32, in_channels % 16 == 0, hw % 128 == 0; otherwise PCT_ERR_UNSUPPORTED.
+ * Four launches on `stream`. */
+PCT_API int pct_conv1x1_groupnorm_tokens_f32(const float *x, const float *w, const float *bias, void *w_split_ws,
+                                             const float *gamma, const float *beta, int groups, float eps, int batch,
+                                             int in_channels, int out_channels, int hw, float *partial_ws, float *stats,
+                                             float *out, long long out_batch_stride, long long out_offset, void *stream);
+
 /* ---- 1x1 convolution on NCHW maps, fp32-accurate on the bf16 matrix cores (csrc/conv1x1_split.hip) -------------------
  * Replaces the `Conv2d(in_channels, conv_dim, kernel_size=1)` of the pixel decoder's input projections and FPN laterals
  * (pixel_decoder/msdeformattn.py:213-226, :262-277) for contiguous fp32 maps:

@@ -45,6 +45,8 @@ const char *msda_backward_col_build_flags();
 int launch_msda_forward_planes(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int, int,
                                int, int, int, void *, hipStream_t, const float *, long long);
 int launch_conv1x1_nchw_split(const float *, const float *, const float *, unsigned short *, int, int, int, float *, hipStream_t);
+int launch_conv1x1_groupnorm_tokens(const float *, const float *, const float *, unsigned short *, const float *, const float *, float,
+                                    int, int, int, float *, float *, float *, long long, hipStream_t);
 int launch_cross_attention(const void *, const void *, const void *, const void *, const void *, const unsigned char *,
                            const unsigned char *, int, int, int, int, float, void *, hipStream_t);
 int launch_masked_attention(const void *, const void *, const void *, const unsigned char *, int, int, int, int, int,
@@ -426,6 +428,24 @@ int pct_conv1x1_nchw_f32(const float *x, const float *w, const float *bias, void
   if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)w_split_ws | (uintptr_t)out | (uintptr_t)bias) & 15u) return PCT_ERR_ALIGNMENT;
   const int rc = pct::launch_conv1x1_nchw_split(x, w, bias, static_cast<unsigned short *>(w_split_ws), batch, in_channels, hw, out,
                                                 static_cast<hipStream_t>(stream));
+  return rc == -4 ? PCT_ERR_UNSUPPORTED : rc;
+}
+
+int pct_conv1x1_groupnorm_tokens_f32(const float *x, const float *w, const float *bias, void *w_split_ws, const float *gamma,
+                                     const float *beta, int groups, float eps, int batch, int in_channels, int out_channels, int hw,
+                                     float *partial_ws, float *stats, float *out, long long out_batch_stride, long long out_offset,
+                                     void *stream)
+{
+  if (batch < 0 || in_channels <= 0 || out_channels <= 0 || hw < 0 || out_batch_stride < 0 || out_offset < 0) return PCT_ERR_BAD_ARG;
+  if (batch == 0 || hw == 0) return PCT_OK;
+  if (!x || !w || !w_split_ws || !gamma || !beta || !partial_ws || !stats || !out) return PCT_ERR_BAD_ARG;
+  if (out_channels != 128 || groups != 32) return PCT_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)w_split_ws | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)gamma | (uintptr_t)beta |
+        (uintptr_t)partial_ws | (uintptr_t)stats) & 15u) || (out_batch_stride & 3) || (out_offset & 3))
+    return PCT_ERR_ALIGNMENT;
+  const int rc = pct::launch_conv1x1_groupnorm_tokens(x, w, bias, static_cast<unsigned short *>(w_split_ws), gamma, beta, eps, batch,
+                                                      in_channels, hw, partial_ws, stats, out + out_offset, out_batch_stride,
+                                                      static_cast<hipStream_t>(stream));
   return rc == -4 ? PCT_ERR_UNSUPPORTED : rc;
 }
 

@@ -68,10 +68,20 @@ __global__ __launch_bounds__(256) void conv1x1_split_weights_kernel(const float 
   *reinterpret_cast<unsigned *>(ws + base + C1_WPLANE) = p3;
 }
 
+// TOKENS: the output goes to the encoder's token rows instead -- y[n][row_offset + p][co], channels fastest, which is what a lane
+// holds (4 consecutive channels of one pixel per accumulator quartet: 16-byte stores, 16 per lane instead of 64 dword stores) --
+// and the GroupNorm(32, 128) that follows the projection (msdeformattn.py:220-224) gets its statistics from here: 4 channels per
+// group = exactly one accumulator quartet, so a wave forms (mean, sum of centred squares) of its 256 values per group in
+// registers (two passes, as gn_stats_kernel does over the whole map) and writes them as a partial record; gn_finalize_kernel
+// combines the records of an image (Chan's formula), gn_apply_tokens_kernel normalises the rows in place.  The [N, 128, H, W]
+// intermediate, its two re-reads and the transposing copy are gone.
+template <bool TOKENS>
 __global__ __launch_bounds__(C1_BLOCK, 2) void conv1x1_nchw_split_kernel(const float *__restrict__ x,
                                                                          const unsigned short *__restrict__ ws,
                                                                          const float *__restrict__ bias, const int K,
-                                                                         const int HW, float *__restrict__ y)
+                                                                         const int HW, float *__restrict__ y,
+                                                                         const long long y_batch_stride,
+                                                                         float *__restrict__ partial)
 {
   __shared__ __attribute__((aligned(16))) unsigned char xs[2][C1_XBUF];
   __shared__ __attribute__((aligned(16))) unsigned char wsm[2][C1_WBUF];
@@ -172,8 +182,49 @@ __global__ __launch_bounds__(C1_BLOCK, 2) void conv1x1_nchw_split_kernel(const f
     __syncthreads();
   }
 
-  // epilogue: acc[4 q + t] = y[co = block + 8 q + 4 h + t][pixel = block + r]; a wave instruction writes 32 consecutive pixels
-  // of two channels (128 B each)
+  // epilogue: acc[4 q + t] = y[co = block + 8 q + 4 h + t][pixel = block + r]
+  if constexpr (TOKENS) {
+    float *yn = y + (size_t)n * y_batch_stride + (size_t)p0 * C1_CO;          // (y already points at the level's first row)
+    const int tile = blockIdx.x - n * tiles;
+    float *prec = partial + ((size_t)((size_t)n * tiles + tile) * 2 + px_half) * 64;      // [32 groups][mean, M2] of this wave pair
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int co0 = co_half * 64 + rb * 32 + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const c1_f32x4 bq = bias ? *reinterpret_cast<const c1_f32x4 *>(bias + co0 + 8 * q) : c1_f32x4{0.f, 0.f, 0.f, 0.f};
+        c1_f32x4 v[2];
+        float sm = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[cb][t] = (acc_hi[rb][cb][4 * q + t] + acc_lo[rb][cb][4 * q + t]) + bq[t];
+          sm += (v[cb][0] + v[cb][1]) + (v[cb][2] + v[cb][3]);
+          *reinterpret_cast<c1_f32x4 *>(yn + (size_t)(px_half * 64 + cb * 32 + r) * C1_CO + co0 + 8 * q) = v[cb];
+        }
+        // the group's 256 values of this wave: 8 per lane over the 32 lanes of a half wave (same h)
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) sm += __shfl_xor(sm, o);
+        const float mean = sm * (1.f / 256.f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float d = v[cb][t] - mean;
+            m2 += d * d;
+          }
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) m2 += __shfl_xor(m2, o);
+        if (r == 0) {
+          const int g = co_half * 16 + rb * 8 + 2 * q + h;
+          *reinterpret_cast<c1_f32x2 *>(prec + 2 * g) = c1_f32x2{mean, m2};
+        }
+      }
+    }
+    return;
+  }
+  // a wave instruction writes 32 consecutive pixels of two channels (128 B each)
   float *yn = y + (size_t)n * C1_CO * HW + p0;
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
@@ -194,6 +245,50 @@ __global__ __launch_bounds__(C1_BLOCK, 2) void conv1x1_nchw_split_kernel(const f
   }
 }
 
+// ---- GroupNorm(32, 128) on token rows from the partial records of conv1x1_nchw_split_kernel<true> --------------------------
+// stats[(n * 32 + g) * 2 + {0, 1}] = mean, rstd: one wave per (image, group) combines T records of 256 values each
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict__ partial, const int T, const float eps,
+                                                         float *__restrict__ stats)
+{
+  const int n = blockIdx.x >> 5, g = blockIdx.x & 31, lane = threadIdx.x;
+  const float *p = partial + (size_t)n * T * 64 + 2 * g;
+  float sm = 0.f;
+  for (int t = lane; t < T; t += 64) sm += p[(size_t)t * 64];
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) sm += __shfl_xor(sm, o);
+  const float mean = sm / (float)T;
+  float m2 = 0.f;
+  for (int t = lane; t < T; t += 64) {
+    const float d = p[(size_t)t * 64] - mean;
+    m2 += p[(size_t)t * 64 + 1] + 256.f * d * d;
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) m2 += __shfl_xor(m2, o);
+  if (lane == 0) {
+    stats[2 * blockIdx.x] = mean;
+    stats[2 * blockIdx.x + 1] = rsqrtf(m2 / (256.f * (float)T) + eps);
+  }
+}
+
+// rows [n][p][128] in place: one thread per (row, group of 4 channels)
+__global__ __launch_bounds__(256) void gn_apply_tokens_kernel(float *__restrict__ y, const long long y_batch_stride, const int HW,
+                                                              const float *__restrict__ stats, const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta)
+{
+  const int n = blockIdx.y;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;              // float4 index inside the level's rows of image n
+  if (i >= (long long)HW * 32) return;
+  const int g = (int)(i & 31);
+  const float mean = stats[2 * (n * 32 + g)], rstd = stats[2 * (n * 32 + g) + 1];
+  const c1_f32x4 ga = *reinterpret_cast<const c1_f32x4 *>(gamma + 4 * g), be = *reinterpret_cast<const c1_f32x4 *>(beta + 4 * g);
+  c1_f32x4 *p = reinterpret_cast<c1_f32x4 *>(y + (size_t)n * y_batch_stride) + i;
+  const c1_f32x4 v = *p;
+  c1_f32x4 o;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) o[t] = (v[t] - mean) * rstd * ga[t] + be[t];
+  *p = o;
+}
+
 // -4: geometry not covered (the caller keeps the library convolution)
 int launch_conv1x1_nchw_split(const float *x, const float *w, const float *bias, unsigned short *w_split_ws, int N, int K, int HW,
                               float *y, hipStream_t stream)
@@ -203,8 +298,28 @@ int launch_conv1x1_nchw_split(const float *x, const float *w, const float *bias,
   if ((long long)N * (HW / C1_PT) >= 0x7fffffffLL) return -4;
   hipLaunchKernelGGL(conv1x1_split_weights_kernel, dim3((unsigned)((C1_CO * K / 2 + 255) / 256)), dim3(256), 0, stream, w, K,
                      w_split_ws);
-  hipLaunchKernelGGL(conv1x1_nchw_split_kernel, dim3((unsigned)(N * (HW / C1_PT))), dim3(C1_BLOCK), 0, stream, x, w_split_ws,
-                     bias, K, HW, y);
+  hipLaunchKernelGGL(conv1x1_nchw_split_kernel<false>, dim3((unsigned)(N * (HW / C1_PT))), dim3(C1_BLOCK), 0, stream, x, w_split_ws,
+                     bias, K, HW, y, 0LL, static_cast<float *>(nullptr));
+  return (int)hipGetLastError();
+}
+
+// 1x1 projection + GroupNorm(32, 128) + flatten into token rows: out[n][p][128] at `out` (the level's first row of image 0),
+// images out_batch_stride floats apart.  partial_ws: N * (HW / 128) * 2 * 64 floats; stats: N * 64 floats.  Four launches.
+int launch_conv1x1_groupnorm_tokens(const float *x, const float *w, const float *bias, unsigned short *w_split_ws, const float *gamma,
+                                    const float *beta, float eps, int N, int K, int HW, float *partial_ws, float *stats,
+                                    float *out, long long out_batch_stride, hipStream_t stream)
+{
+  if (N == 0) return 0;
+  if (K % C1_KS != 0 || HW % C1_PT != 0 || K <= 0) return -4;
+  if ((long long)N * (HW / C1_PT) >= 0x7fffffffLL || N > 65535) return -4;
+  const int tiles = HW / C1_PT;
+  hipLaunchKernelGGL(conv1x1_split_weights_kernel, dim3((unsigned)((C1_CO * K / 2 + 255) / 256)), dim3(256), 0, stream, w, K,
+                     w_split_ws);
+  hipLaunchKernelGGL(conv1x1_nchw_split_kernel<true>, dim3((unsigned)(N * tiles)), dim3(C1_BLOCK), 0, stream, x, w_split_ws, bias, K,
+                     HW, out, out_batch_stride, partial_ws);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(N * 32)), dim3(64), 0, stream, partial_ws, 2 * tiles, eps, stats);
+  hipLaunchKernelGGL(gn_apply_tokens_kernel, dim3((unsigned)(((long long)HW * 32 + 255) / 256), (unsigned)N), dim3(256), 0, stream, out,
+                     out_batch_stride, HW, stats, gamma, beta);
   return (int)hipGetLastError();
 }
 

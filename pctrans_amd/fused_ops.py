@@ -285,6 +285,34 @@ def conv1x1_nchw(x, conv):
     return out
 
 
+def conv1x1_groupnorm_tokens_supported(x, conv, gn):
+    """conv1x1_nchw_supported + an affine GroupNorm(32, 128) behind the convolution."""
+    return (conv1x1_nchw_supported(x, conv) and isinstance(gn, torch.nn.GroupNorm) and gn.num_groups == 32
+            and gn.num_channels == 128 and gn.weight is not None and gn.bias is not None
+            and gn.weight.data_ptr() % 16 == 0 and gn.bias.data_ptr() % 16 == 0 and x.shape[0] <= 65535
+            and not (torch.is_grad_enabled() and gn.weight.requires_grad))
+
+
+def conv1x1_groupnorm_tokens_into(x, conv, gn, out, row_offset):
+    """out[:, row_offset : row_offset + H*W, :] = gn(conv(x)).flatten(2).transpose(1, 2)  (out: [N, S, 128] contiguous fp32):
+    the pixel decoder's input projection of one level in one entry (csrc/conv1x1_split.hip)."""
+    n, k, h, w_ = x.shape
+    hw = h * w_
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    key = (x.device, stream, k)
+    ws = _CONV_WS.get(key)
+    if ws is None:
+        ws = _CONV_WS[key] = torch.empty((3, 128, k), dtype=torch.bfloat16, device=x.device)
+    partial = torch.empty((n * (hw // 128) * 2 * 64,), dtype=torch.float32, device=x.device)
+    stats = torch.empty((n * 64,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timing.timed("conv1x1_gn k=%d" % k, x):
+        rc = _lib.lib().pct_conv1x1_groupnorm_tokens_f32(
+            x.data_ptr(), conv.weight.data_ptr(), conv.bias.data_ptr() if conv.bias is not None else None, ws.data_ptr(),
+            gn.weight.data_ptr(), gn.bias.data_ptr(), 32, float(gn.eps), n, k, 128, hw, partial.data_ptr(), stats.data_ptr(),
+            out.data_ptr(), out.stride(0), row_offset * 128, stream)
+    _lib.check(rc, "conv1x1_groupnorm_tokens")
+
+
 def groupnorm_flatten_supported(x, gn):
     """fp32 NCHW device tensor, 128 channels, groups of a multiple of 4 channels, affine, forward only."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 128 and x.is_contiguous()

@@ -262,20 +262,32 @@ class MSDeformAttnPixelDecoder(nn.Module):
         with torch.autocast(device_type=dev_type, enabled=False):
             srcs, pos = [], []
             xs = [features[f].float() for f in self.transformer_in_features[::-1]]
-            convs = [fused_ops.conv1x1_nchw(x, self.input_proj[idx][0]) for idx, x in enumerate(xs)]
             src_flatten = None
-            if all(fused_ops.groupnorm_flatten_supported(c, self.input_proj[idx][1]) for idx, c in enumerate(convs)):
-                # GroupNorm + flatten(2).transpose(1, 2) + the concat over the levels in one pass per level
-                sizes = [c.shape[2] * c.shape[3] for c in convs]
-                src_flatten = torch.empty((convs[0].shape[0], sum(sizes), convs[0].shape[1]), dtype=torch.float32,
-                                          device=convs[0].device)
+            sizes = [x.shape[2] * x.shape[3] for x in xs]
+            if all(fused_ops.conv1x1_groupnorm_tokens_supported(x, self.input_proj[idx][0], self.input_proj[idx][1])
+                   for idx, x in enumerate(xs)):
+                # 1x1 projection + GroupNorm + flatten(2).transpose(1, 2) + the concat over the levels: one entry per level, the
+                # [N, 128, H, W] intermediate never exists (csrc/conv1x1_split.hip)
+                import types
+                src_flatten = torch.empty((xs[0].shape[0], sum(sizes), 128), dtype=torch.float32, device=xs[0].device)
                 start = 0
-                for idx, c in enumerate(convs):
-                    fused_ops.groupnorm_flatten_into(c, self.input_proj[idx][1], src_flatten, start)
+                for idx, x in enumerate(xs):
+                    fused_ops.conv1x1_groupnorm_tokens_into(x, self.input_proj[idx][0], self.input_proj[idx][1], src_flatten, start)
                     start += sizes[idx]
-                srcs = convs                                       # only their shapes are used from here on
+                srcs = [types.SimpleNamespace(shape=(x.shape[0], 128, x.shape[2], x.shape[3])) for x in xs]
             else:
-                srcs = [self.input_proj[idx][1](c) for idx, c in enumerate(convs)]
+                convs = [fused_ops.conv1x1_nchw(x, self.input_proj[idx][0]) for idx, x in enumerate(xs)]
+                if all(fused_ops.groupnorm_flatten_supported(c, self.input_proj[idx][1]) for idx, c in enumerate(convs)):
+                    # GroupNorm + flatten(2).transpose(1, 2) + the concat over the levels in one pass per level
+                    src_flatten = torch.empty((convs[0].shape[0], sum(sizes), convs[0].shape[1]), dtype=torch.float32,
+                                              device=convs[0].device)
+                    start = 0
+                    for idx, c in enumerate(convs):
+                        fused_ops.groupnorm_flatten_into(c, self.input_proj[idx][1], src_flatten, start)
+                        start += sizes[idx]
+                    srcs = convs                                       # only their shapes are used from here on
+                else:
+                    srcs = [self.input_proj[idx][1](c) for idx, c in enumerate(convs)]
             pos = [self.pe_layer(x) for x in xs]
 
             y, spatial_shapes, level_start_index = self.transformer(srcs, pos, src_flatten=src_flatten)

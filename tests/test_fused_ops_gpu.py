@@ -620,3 +620,30 @@ def test_conv1x1_nchw_falls_back_where_the_kernel_does_not_apply():
     conv3 = Conv2d(64, 128, kernel_size=3, padding=1).cuda()
     assert not fused_ops.conv1x1_nchw_supported(torch.randn(1, 64, 16, 8, device="cuda"), conv3)
     assert not fused_ops.conv1x1_nchw_supported(torch.randn(1, 64, 16, 8, device="cuda").requires_grad_(), conv)
+
+
+@pytest.mark.parametrize("N,K,H,W", [(2, 256, 32, 32), (3, 512, 16, 24), (1, 2048, 16, 16), (2, 32, 8, 16)])
+def test_conv1x1_groupnorm_tokens_equals_the_module_chain(N, K, H, W):
+    """Input projection in one entry (csrc/conv1x1_split.hip, token epilogue + per-tile GroupNorm records + in-place
+    normalisation) against nn.Sequential(Conv2d(K, 128, 1), GroupNorm(32, 128)) + flatten(2).transpose(1, 2) in fp64, written at
+    a row offset of a larger token buffer whose other rows must stay untouched (pixel_decoder/msdeformattn.py:213-226, 75-83)."""
+    from pctrans_amd.layers import Conv2d
+    torch.manual_seed(N * K + W)
+    conv = Conv2d(K, 128, kernel_size=1).cuda()
+    gn = torch.nn.GroupNorm(32, 128).cuda()
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.uniform_(-0.5, 0.5)
+        conv.bias.uniform_(-2.0, 2.0)                           # group means far from zero: the variance must not cancel
+    x = torch.randn(N, K, H, W, device="cuda") + 0.5
+    S, off = H * W + 40, 24
+    out = torch.full((N, S, 128), 7.0, device="cuda")
+    with torch.no_grad():
+        assert fused_ops.conv1x1_groupnorm_tokens_supported(x, conv, gn)
+        fused_ops.conv1x1_groupnorm_tokens_into(x, conv, gn, out, off)
+        ref = torch.nn.functional.group_norm(
+            torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double()), 32, gn.weight.double(),
+            gn.bias.double(), gn.eps).flatten(2).transpose(1, 2)
+    assert float((out[:, :off] - 7.0).abs().max()) == 0.0 and float((out[:, off + H * W:] - 7.0).abs().max()) == 0.0
+    err = float((out[:, off:off + H * W].double() - ref).abs().max())
+    assert err <= 2e-5, err
