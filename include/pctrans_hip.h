@@ -267,6 +267,18 @@ PCT_API int pct_linear_add_layernorm_f32(const float *x, long long ldx, int k, c
                                          const float *beta, float eps, long long rows, float *out, long long ldo,
                                          void *stream);
 
+/* ---- the encoder layer's feed-forward block in one kernel (csrc/ffn_fused_split.hip) -------------------------------------
+ * Replaces linear1 -> ReLU -> dropout2 -> linear2 -> `src + dropout3(src2)` -> norm2 (pixel_decoder/msdeformattn.py:122-131) in
+ * eval mode (dropout is the identity):   out = LayerNorm(x + W2 . relu(W1 . x + b1) + b2)
+ *   x, out [rows, 128] fp32 (row strides ldx, ldo floats); w1 [hidden, 128], b1 [hidden], w2 [128, hidden], b2 [128] or NULL,
+ *   gamma / beta [128]; hidden % 32 == 0
+ *   w_image_ws: device workspace of (hidden / 32) * 57 344 bytes, refilled on every call (one per stream)
+ * fp32-accurate (exact three-way bf16 splits on the matrix cores, as the Linear entries); the [rows, hidden] activations stay
+ * in registers between the two products.  Two launches on `stream`. */
+PCT_API int pct_ffn_layernorm_f32(const float *x, long long ldx, const float *w1, const float *b1, const float *w2,
+                                  const float *b2, const float *gamma, const float *beta, float eps, int hidden,
+                                  long long rows, void *w_image_ws, float *out, long long ldo, void *stream);
+
 /* ---- input projection of the pixel decoder in one entry: 1x1 convolution + GroupNorm(32, 128) + flatten into token rows ----
  * Replaces `nn.Sequential(Conv2d(in_channels, 128, kernel_size=1), nn.GroupNorm(32, 128))` followed by
  * `.flatten(2).transpose(1, 2)` and the concat over the levels (pixel_decoder/msdeformattn.py:213-226, 75-83):

@@ -43,6 +43,8 @@ SYMBOLS = {
     "pct_conv1x1_nchw_f32": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp], _i),
     "pct_conv1x1_groupnorm_tokens_f32": ([_vp] * 6 + [_i, ctypes.c_float] + [_i] * 4 + [_vp, _vp, _vp, ctypes.c_longlong,
                                           ctypes.c_longlong, _vp], _i),
+    "pct_ffn_layernorm_f32": ([_vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i, ctypes.c_longlong, _vp, _vp,
+                               ctypes.c_longlong, _vp], _i),
     "pct_lsap_f32": ([_vp, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
     "pct_cross_attention_bf16": ([_vp] * 7 + [_i] * 4 + [ctypes.c_float, _vp, _vp], _i),
     "pct_masked_attention_bf16": ([_vp, _vp, _vp, _vp] + [_i] * 6 + [ctypes.c_float, _i, _vp, _vp], _i),

@@ -44,6 +44,8 @@ const char *msda_forward_col_build_flags();
 const char *msda_backward_col_build_flags();
 int launch_msda_forward_planes(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int, int,
                                int, int, int, void *, hipStream_t, const float *, long long);
+int launch_ffn_fused_split(const float *, long long, const float *, const float *, const float *, const float *, const float *,
+                           const float *, float, int, long long, void *, float *, long long, hipStream_t);
 int launch_conv1x1_nchw_split(const float *, const float *, const float *, unsigned short *, int, int, int, float *, hipStream_t);
 int launch_conv1x1_groupnorm_tokens(const float *, const float *, const float *, unsigned short *, const float *, const float *, float,
                                     int, int, int, float *, float *, float *, long long, hipStream_t);
@@ -446,6 +448,22 @@ int pct_conv1x1_groupnorm_tokens_f32(const float *x, const float *w, const float
   const int rc = pct::launch_conv1x1_groupnorm_tokens(x, w, bias, static_cast<unsigned short *>(w_split_ws), gamma, beta, eps, batch,
                                                       in_channels, hw, partial_ws, stats, out + out_offset, out_batch_stride,
                                                       static_cast<hipStream_t>(stream));
+  return rc == -4 ? PCT_ERR_UNSUPPORTED : rc;
+}
+
+int pct_ffn_layernorm_f32(const float *x, long long ldx, const float *w1, const float *b1, const float *w2, const float *b2,
+                          const float *gamma, const float *beta, float eps, int hidden, long long rows, void *w_image_ws, float *out,
+                          long long ldo, void *stream)
+{
+  if (rows < 0 || hidden <= 0 || ldx < 128 || ldo < 128) return PCT_ERR_BAD_ARG;
+  if (rows == 0) return PCT_OK;
+  if (!x || !w1 || !b1 || !w2 || !gamma || !beta || !w_image_ws || !out) return PCT_ERR_BAD_ARG;
+  if (hidden % 32) return PCT_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)b1 | (uintptr_t)w2 | (uintptr_t)b2 | (uintptr_t)gamma | (uintptr_t)beta |
+        (uintptr_t)w_image_ws | (uintptr_t)out) & 15u) || (ldx & 3) || (ldo & 3))
+    return PCT_ERR_ALIGNMENT;
+  const int rc = pct::launch_ffn_fused_split(x, ldx, w1, b1, w2, b2, gamma, beta, eps, hidden, rows, w_image_ws, out, ldo,
+                                             static_cast<hipStream_t>(stream));
   return rc == -4 ? PCT_ERR_UNSUPPORTED : rc;
 }
 

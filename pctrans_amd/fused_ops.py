@@ -247,6 +247,45 @@ def linear_layer_norm(x, linear, residual, norm):
     return out.view(residual.shape)
 
 
+_FFN_WS = {}                  # (device, stream, hidden) -> weight-image workspace of ffn_layer_norm (refilled per call)
+
+
+def ffn_layer_norm_supported(x, linear1, linear2, norm):
+    """fp32 device rows of width 128 through Linear(128 -> F) + ReLU + Linear(F -> 128) + residual + LayerNorm(128), F % 32 == 0,
+    forward only (csrc/ffn_fused_split.hip)."""
+    w1, w2 = linear1.weight, linear2.weight
+    return (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 128 and x.stride(-1) == 1 and x.numel() > 0
+            and w1.dtype == torch.float32 and w2.dtype == torch.float32 and w1.device == x.device and w2.device == x.device
+            and w1.is_contiguous() and w2.is_contiguous() and linear1.in_features == 128 and linear2.out_features == 128
+            and linear1.out_features == linear2.in_features and linear1.out_features % 32 == 0
+            and linear1.bias is not None and isinstance(norm, torch.nn.LayerNorm) and tuple(norm.normalized_shape) == (128,)
+            and norm.weight is not None and norm.bias is not None and not torch.is_autocast_enabled()
+            and not (torch.is_grad_enabled() and (x.requires_grad or w1.requires_grad or w2.requires_grad)))
+
+
+def ffn_layer_norm(x, linear1, linear2, norm):
+    """norm(x + linear2(relu(linear1(x)))): the encoder FFN in one kernel; the [rows, F] hidden tensor never goes to memory."""
+    x2 = _rows_2d(x)
+    rows = x2.shape[0]
+    f = linear1.out_features
+    ptrs = [x2, linear1.weight, linear1.bias, linear2.weight, norm.weight, norm.bias] + ([linear2.bias] if linear2.bias is not None else [])
+    if not (all(t.data_ptr() % 16 == 0 for t in ptrs) and x2.stride(0) % 4 == 0):
+        return linear_layer_norm(linear(x, linear1, relu=True), linear2, x, norm)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    key = (x.device, stream, f)
+    ws = _FFN_WS.get(key)
+    if ws is None:
+        ws = _FFN_WS[key] = torch.empty(((f // 32) * 57344,), dtype=torch.uint8, device=x.device)
+    out = torch.empty((rows, 128), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timing.timed("ffn f=%d" % f, x2):
+        rc = _lib.lib().pct_ffn_layernorm_f32(
+            x2.data_ptr(), x2.stride(0), linear1.weight.data_ptr(), linear1.bias.data_ptr(), linear2.weight.data_ptr(),
+            linear2.bias.data_ptr() if linear2.bias is not None else None, norm.weight.data_ptr(), norm.bias.data_ptr(),
+            float(norm.eps), f, rows, ws.data_ptr(), out.data_ptr(), 128, stream)
+    _lib.check(rc, "ffn_layer_norm")
+    return out.view(x.shape)
+
+
 _CONV_WS = {}                 # (device, stream, in_channels) -> split-weight workspace of conv1x1_nchw (refilled per call)
 
 

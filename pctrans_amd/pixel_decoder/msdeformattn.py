@@ -69,6 +69,9 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
 
     def forward_ffn(self, src):
         if self._eval_fused(src):
+            if fused_ops.ffn_layer_norm_supported(src, self.linear1, self.linear2, self.norm2):
+                # the whole block in one kernel: the [rows, d_ffn] hidden tensor stays in registers
+                return fused_ops.ffn_layer_norm(src, self.linear1, self.linear2, self.norm2)
             return fused_ops.linear_layer_norm(fused_ops.linear(src, self.linear1, relu=True), self.linear2, src, self.norm2)
         src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
         return self.norm2(src + self.dropout3(src2))

@@ -647,3 +647,30 @@ def test_conv1x1_groupnorm_tokens_equals_the_module_chain(N, K, H, W):
     assert float((out[:, :off] - 7.0).abs().max()) == 0.0 and float((out[:, off + H * W:] - 7.0).abs().max()) == 0.0
     err = float((out[:, off:off + H * W].double() - ref).abs().max())
     assert err <= 2e-5, err
+
+
+@pytest.mark.parametrize("rows,F", [(128, 1024), (4000, 1024), (37, 64), (257, 2048)])
+def test_fused_ffn_is_as_accurate_as_fp32(rows, F):
+    """The encoder layer's FFN in one kernel (csrc/ffn_fused_split.hip: the hidden activations stay in registers between the two
+    split-bf16 products) against fp64 and against the fp32 module chain norm2(x + linear2(relu(linear1(x))))
+    (pixel_decoder/msdeformattn.py:122-131): error no larger than twice the fp32 chain's own."""
+    torch.manual_seed(rows + F)
+    l1, l2 = torch.nn.Linear(128, F).cuda(), torch.nn.Linear(F, 128).cuda()
+    norm = torch.nn.LayerNorm(128).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+        l1.weight.mul_(2.0)
+    x = torch.randn(rows, 128, device="cuda") * torch.logspace(-1, 1, 128, device="cuda")
+    with torch.no_grad():
+        assert fused_ops.ffn_layer_norm_supported(x, l1, l2, norm)
+        got = fused_ops.ffn_layer_norm(x, l1, l2, norm)
+        xd = x.double()
+        hid = torch.relu(xd @ l1.weight.double().t() + l1.bias.double())
+        ref = torch.nn.functional.layer_norm(xd + hid @ l2.weight.double().t() + l2.bias.double(), (128,), norm.weight.double(),
+                                             norm.bias.double(), norm.eps)
+        chain = norm(x + l2(torch.relu(l1(x))))
+    err = float((got.double() - ref).abs().max())
+    err32 = float((chain.double() - ref).abs().max())
+    assert torch.isfinite(got).all() and got.shape == x.shape
+    assert err <= max(2.0 * err32, 5e-6), (err, err32)
