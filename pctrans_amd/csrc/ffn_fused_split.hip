@@ -25,6 +25,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
+
+// knock-outs (WRONG RESULTS, timing only): 1 = no image transport inside the chunk loop, 2 = no bias / ReLU / split arithmetic,
+// 4 = no barrier per chunk, 16 / 32 = of the transport only the LDS stores / only the loads
+#ifndef PCT_FFN_KO
+#define PCT_FFN_KO 0
+#endif
+#if PCT_FFN_KO && !defined(PCT_EXPERIMENT_BUILD)
+#error "PCT_FFN_KO gives wrong results: add -DPCT_EXPERIMENT_BUILD"
+#endif
 
 namespace pct {
 
@@ -46,6 +56,8 @@ constexpr int FF_W2PLANE = FF_D * FF_W2ROW;       // 10 240
 constexpr int FF_W2OFF = 3 * FF_W1PLANE;          // 26 112
 constexpr int FF_STAGE = 57344;                   // 26 112 + 30 720 = 56 832, padded to 256 threads x 14 x 16 B
 constexpr int FF_PIECES = FF_STAGE / (FF_BLOCK * 16);   // 14
+constexpr int FF_HALF = FF_PIECES / 2;                  // 7
+constexpr int FF_B1OFF = 56832;                         // the chunk's 32 biases, in the padding
 
 __device__ __forceinline__ void ff_split(const float x, const float y, unsigned &p1, unsigned &p2, unsigned &p3)
 {
@@ -67,18 +79,21 @@ __device__ __forceinline__ void ff_split8(const ff_f32x4 a, const ff_f32x4 b, ff
   for (int q = 0; q < 3; ++q) out[q] = __builtin_bit_cast(ff_bf16x8, ff_i32x4{(int)p[q][0], (int)p[q][1], (int)p[q][2], (int)p[q][3]});
 }
 
-// W1 [F][128], W2 [128][F] fp32 -> img [F / 32][FF_STAGE bytes]: the LDS image of every chunk (see the header); one thread per
-// element pair of either matrix
-__global__ __launch_bounds__(256) void ffn_split_weights_kernel(const float *__restrict__ w1, const float *__restrict__ w2, const int F,
+// W1 [F][128], W2 [128][F], b1 [F] fp32 -> img [F / 32][FF_STAGE bytes]: image c holds W2 and b1 of chunk c and W1 of chunk c + 1
+// (mod F / 32): what one iteration of the kernel's chunk loop reads (see the header); one thread per element pair
+__global__ __launch_bounds__(256) void ffn_split_weights_kernel(const float *__restrict__ w1, const float *__restrict__ w2,
+                                                                const float *__restrict__ b1, const int F,
                                                                 unsigned short *__restrict__ img)
 {
   const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
   const long long n1 = (long long)F * FF_D;
+  const int nch = F / FF_CH;
   unsigned p1, p2, p3;
-  if (e < n1) {                                                   // W1[u][k], k even: chunk u / 32, row u % 32, k-contiguous
+  if (e < n1) {                                                   // W1[u][k], k even: row u % 32, k-contiguous
     const int u = (int)(e / FF_D), k = (int)(e - (long long)u * FF_D);
     ff_split(w1[e], w1[e + 1], p1, p2, p3);
-    unsigned short *d = img + (size_t)(u / FF_CH) * (FF_STAGE / 2) + (size_t)(u % FF_CH) * (FF_W1ROW / 2) + k;
+    const int c = (u / FF_CH + nch - 1) % nch;
+    unsigned short *d = img + (size_t)c * (FF_STAGE / 2) + (size_t)(u % FF_CH) * (FF_W1ROW / 2) + k;
     *reinterpret_cast<unsigned *>(d) = p1;
     *reinterpret_cast<unsigned *>(d + FF_W1PLANE / 2) = p2;
     *reinterpret_cast<unsigned *>(d + FF_W1PLANE) = p3;
@@ -96,12 +111,17 @@ __global__ __launch_bounds__(256) void ffn_split_weights_kernel(const float *__r
     *reinterpret_cast<unsigned *>(d) = p1;                        // (t even: t and t + 1 are adjacent slots)
     *reinterpret_cast<unsigned *>(d + FF_W2PLANE / 2) = p2;
     *reinterpret_cast<unsigned *>(d + FF_W2PLANE) = p3;
+  } else if (e < 2 * n1 + F) {                                    // b1[u], u even
+    const int u = (int)(e - 2 * n1);
+    float *d = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(img) + (size_t)(u / FF_CH) * FF_STAGE + FF_B1OFF) + u % FF_CH;
+    d[0] = b1[u];
+    d[1] = b1[u + 1];
   }
 }
 
 __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
     const float *__restrict__ X, const long long ldx, const unsigned short *__restrict__ img, const int F,
-    const float *__restrict__ b1, const float *__restrict__ b2, const float *__restrict__ gamma, const float *__restrict__ beta,
+    const float *__restrict__ b2, const float *__restrict__ gamma, const float *__restrict__ beta,
     const float eps, const long long M, float *__restrict__ Y, const long long ldy)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char ff_smem[];    // two stages
@@ -113,15 +133,23 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
 
   const auto img_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(img), 0, (int)((long long)nch * FF_STAGE),
                                                           0x00020000);
-  ff_i32x4 gst[FF_PIECES];                                        // the next chunk's image on its way to LDS
-  auto fetch_stage = [&](const int chunk) {
+  // an image travels to LDS through registers in two halves of seven 16-byte pieces per thread
+  ff_i32x4 gst[FF_HALF];
+  bool transport = true;
+  auto fetch_half = [&](const int chunk, const int half) {
+    if ((PCT_FFN_KO & 1) && !transport) return;
+    if ((PCT_FFN_KO & 16) && !transport) return;                  // stores only
 #pragma unroll
-    for (int i = 0; i < FF_PIECES; ++i)
-      gst[i] = __builtin_amdgcn_raw_buffer_load_b128(img_rsrc, tid * 16, chunk * FF_STAGE + i * (FF_BLOCK * 16), 0);
+    for (int i = 0; i < FF_HALF; ++i)
+      gst[i] = __builtin_amdgcn_raw_buffer_load_b128(img_rsrc, tid * 16, chunk * FF_STAGE + (half * FF_HALF + i) * (FF_BLOCK * 16), 0);
   };
-  auto store_stage = [&](unsigned char *st) {
-#pragma unroll
-    for (int i = 0; i < FF_PIECES; ++i) *reinterpret_cast<ff_i32x4 *>(st + i * (FF_BLOCK * 16) + tid * 16) = gst[i];
+  auto store_piece = [&](unsigned char *st, const int half, const int i) {
+    if ((PCT_FFN_KO & 1) && !transport) return;
+    if ((PCT_FFN_KO & 32) && !transport) {                        // loads only
+      asm volatile("" ::"v"(gst[i]));
+      return;
+    }
+    *reinterpret_cast<ff_i32x4 *>(st + (half * FF_HALF + i) * (FF_BLOCK * 16) + tid * 16) = gst[i];
   };
 
   // fragment addresses inside a stage: W1 (A operand of GEMM 1): hidden row r, k = 16 s + 8 h ..; W2 (A operand of GEMM 2):
@@ -129,10 +157,20 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
   const int w1_off = r * FF_W1ROW + 16 * h;                       // + 32 s, + plane
   const int w2_off = FF_W2OFF + r * FF_W2ROW + 16 * h;            // + cb * 32 rows, + 32 s, + plane
 
-  fetch_stage(0);
-  store_stage(ff_smem);
+  // stage 1 <- the last image (W1 of chunk 0), stage 0 <- image 0
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    fetch_half(nch - 1, half);
+#pragma unroll
+    for (int i = 0; i < FF_HALF; ++i) store_piece(ff_smem + FF_STAGE, half, i);
+    fetch_half(0, half);
+#pragma unroll
+    for (int i = 0; i < FF_HALF; ++i) store_piece(ff_smem, half, i);
+  }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  int cur = 0;                                                    // stage holding the chunk about to be used
+  int cur = 0;                                                    // stage holding the image of the chunk about to be used
+  fetch_half(1 % nch, 0);                                         // iteration 0 stores image 1
+  transport = false;
 
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // ---- this wave's 32 rows of x as GEMM 1's B fragments: lane (r, h) takes k = 16 s + 8 h .. + 7 of row r ----------------
@@ -156,88 +194,168 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
 #pragma unroll
       for (int j = 0; j < 16; ++j) y_hi[cb][j] = y_lo[cb][j] = 0.f;
 
-    for (int chunk = 0; chunk < nch; ++chunk) {
-      const unsigned char *st = ff_smem + cur * FF_STAGE;
-      // the next chunk's image (the next tile's first one after the last): requested now, stored behind this chunk's MFMAs
-      fetch_stage(chunk + 1 < nch ? chunk + 1 : 0);
-      const ff_f32x4 bq0 = *reinterpret_cast<const ff_f32x4 *>(b1 + chunk * FF_CH + 4 * h);
-      const ff_f32x4 bq1 = *reinterpret_cast<const ff_f32x4 *>(b1 + chunk * FF_CH + 8 + 4 * h);
-      const ff_f32x4 bq2 = *reinterpret_cast<const ff_f32x4 *>(b1 + chunk * FF_CH + 16 + 4 * h);
-      const ff_f32x4 bq3 = *reinterpret_cast<const ff_f32x4 *>(b1 + chunk * FF_CH + 24 + 4 * h);
-      __builtin_amdgcn_sched_barrier(0);
-
-      // ---- GEMM 1: D1[hidden 8 q + 4 h + t][row r] over k = 128.  One wave per SIMD: nobody else covers an LDS round trip, so
-      // the fragments of k-step s + 1 are requested before the MFMAs of step s (the compiler, left alone, read each fragment
-      // right in front of its first MFMA and waited: ~2 400 of a chunk's 5 600 cycles) -----------------------------------------
-      ff_f32x16 h_hi, h_lo;
+    // GEMM 1: D1[hidden 8 q + 4 h + t][row r] over k = 128 from the W1 part of stage `st`.  One wave per SIMD: nobody else covers an
+    // LDS round trip, so the fragments of k-step s + 1 are requested before the MFMAs of step s
+    ff_f32x16 h_hi, h_lo;
+    ff_bf16x8 wa[2][3];
+    auto w1_frags = [&](const unsigned char *st, const int s) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wa[s & 1][p] = *reinterpret_cast<const ff_bf16x8 *>(st + w1_off + 32 * s + p * FF_W1PLANE);
+    };
+    auto gemm1_step = [&](const int s) {
+      const ff_bf16x8 a1 = wa[s & 1][0], a2 = wa[s & 1][1], a3 = wa[s & 1][2];
+      h_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xp[s][2], h_lo, 0, 0, 0);
+      h_hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xp[s][0], h_hi, 0, 0, 0);
+      h_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, xp[s][0], h_lo, 0, 0, 0);
+      h_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xp[s][1], h_lo, 0, 0, 0);
+      h_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xp[s][1], h_lo, 0, 0, 0);
+      h_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xp[s][0], h_lo, 0, 0, 0);
+    };
+    // chunk 0's first product stands alone (its W1 is in the image the previous tile ended on); every later one runs under the
+    // bias / ReLU / split arithmetic of the chunk before it
+    {
+      const unsigned char *pst = ff_smem + (cur ^ 1) * FF_STAGE;
 #pragma unroll
       for (int j = 0; j < 16; ++j) h_hi[j] = h_lo[j] = 0.f;
-      ff_bf16x8 wa[2][3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) wa[0][p] = *reinterpret_cast<const ff_bf16x8 *>(st + w1_off + p * FF_W1PLANE);
+      w1_frags(pst, 0);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        if (s < 7) {
-#pragma unroll
-          for (int p = 0; p < 3; ++p)
-            wa[(s + 1) & 1][p] = *reinterpret_cast<const ff_bf16x8 *>(st + w1_off + 32 * (s + 1) + p * FF_W1PLANE);
-        }
-        const ff_bf16x8 a1 = wa[s & 1][0], a2 = wa[s & 1][1], a3 = wa[s & 1][2];
-        h_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xp[s][2], h_lo, 0, 0, 0);
-        h_hi = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xp[s][0], h_hi, 0, 0, 0);
-        h_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, xp[s][0], h_lo, 0, 0, 0);
-        h_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xp[s][1], h_lo, 0, 0, 0);
-        h_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xp[s][1], h_lo, 0, 0, 0);
-        h_lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xp[s][0], h_lo, 0, 0, 0);
+        if (s < 7) w1_frags(pst, s + 1);
+        gemm1_step(s);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);        // the reads first (left alone the scheduler sinks them)
         __builtin_amdgcn_sched_barrier(0);
       }
-      // GEMM 2's first fragments fly while the hidden values are finished
-      ff_bf16x8 wb[2][3];
+      __builtin_amdgcn_s_barrier();                               // iteration 0 refills that stage
+    }
+
+    // entering iteration `chunk`: wa[0] = step 0 of the W1 fragments and bq = the biases it needs, gst = the first half of image
+    // chunk + 1 on its way
+    ff_f32x4 bq[4];
+    auto load_bias = [&](const unsigned char *st) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wb[0][p] = *reinterpret_cast<const ff_bf16x8 *>(st + w2_off + p * FF_W2PLANE);
-      // ---- bias, ReLU, split: the B fragments of GEMM 2 (k-step s: accumulator quartets 2 s and 2 s + 1) ----------------------
-      ff_bf16x8 hp[2][3];
-      {
-        ff_f32x4 hv[4];
+      for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const ff_f32x4 *>(st + FF_B1OFF + (8 * q + 4 * h) * 4);
+    };
+    w1_frags(ff_smem + cur * FF_STAGE, 0);
+    load_bias(ff_smem + cur * FF_STAGE);
+
+    auto chunk_body = [&](auto last_tag, const int chunk) {
+      constexpr bool LAST = decltype(last_tag)::value;
+      const unsigned char *st = ff_smem + cur * FF_STAGE;         // image `chunk`: W2 and b1 of this chunk, W1 of the next
+      unsigned char *nst = ff_smem + (cur ^ 1) * FF_STAGE;        // nobody reads it since the previous barrier: image chunk + 1
+      const int nxt = LAST ? 0 : chunk + 1;
+      // this chunk's hidden accumulators move to the vector side; the same registers then take the next chunk's product
+      const ff_f32x16 c_hi = h_hi, c_lo = h_lo;
+      if constexpr (!LAST) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          hv[0][t] = fmaxf((h_hi[t] + h_lo[t]) + bq0[t], 0.f);
-          hv[1][t] = fmaxf((h_hi[4 + t] + h_lo[4 + t]) + bq1[t], 0.f);
-          hv[2][t] = fmaxf((h_hi[8 + t] + h_lo[8 + t]) + bq2[t], 0.f);
-          hv[3][t] = fmaxf((h_hi[12 + t] + h_lo[12 + t]) + bq3[t], 0.f);
-        }
-        ff_split8(hv[0], hv[1], hp[0]);
-        ff_split8(hv[2], hv[3], hp[1]);
+        for (int j = 0; j < 16; ++j) h_hi[j] = h_lo[j] = 0.f;
       }
       __builtin_amdgcn_sched_barrier(0);
-      // ---- GEMM 2: D2[col 32 cb + 8 q + 4 h + t][row r] += W2 . h over this chunk's 32 hidden units; group g = (s, cb), the
-      // next group's fragments requested before this group's MFMAs; the next chunk's image goes to the other stage (everyone left
-      // it at the previous barrier) two 16-byte pieces per group -------------------------------------------------------------------
-      unsigned char *nst = ff_smem + (cur ^ 1) * FF_STAGE;
+      // ---- phase A: GEMM 1 of chunk + 1 under bias, ReLU, split of this chunk: step s finishes value pair s of the B fragments of
+      // GEMM 2 (k-step sg = s / 4, word w = s % 4: accumulator quartet q = 2 sg + w / 2, elements 2 (w % 2) and + 1); the first
+      // half of image chunk + 1 (requested a quarter of an iteration ago) is stored in steps 2 - 4, the second half requested -----
+      unsigned hpw[2][3][4];
+      ff_bf16x8 wb[2][3], wc[3];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        if constexpr (!LAST) {
+          if (s < 7) w1_frags(st, s + 1);
+          gemm1_step(s);
+        }
+        if (s == 7) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p) wb[0][p] = *reinterpret_cast<const ff_bf16x8 *>(st + w2_off + p * FF_W2PLANE);
+        }
+        {
+          const int sg = s >> 2, w = s & 3, q = 2 * sg + (w >> 1), t0 = 2 * (w & 1), j0 = 4 * q + t0;
+          const float v0 = fmaxf((c_hi[j0] + c_lo[j0]) + bq[q][t0], 0.f);
+          const float v1 = fmaxf((c_hi[j0 + 1] + c_lo[j0 + 1]) + bq[q][t0 + 1], 0.f);
+          if (PCT_FFN_KO & 2) {
+            hpw[sg][0][w] = __float_as_uint(c_hi[j0]);
+            hpw[sg][1][w] = __float_as_uint(c_lo[j0]);
+            hpw[sg][2][w] = __float_as_uint(c_hi[j0 + 1]) ^ __float_as_uint(c_lo[j0 + 1]);
+          } else
+            ff_split(v0, v1, hpw[sg][0][w], hpw[sg][1][w], hpw[sg][2][w]);
+        }
+        if (s >= 2 && s <= 4) {                                   // three, two, two pieces
+#pragma unroll
+          for (int i = (s == 2 ? 0 : s == 3 ? 3 : 5); i < (s == 2 ? 3 : s == 3 ? 5 : 7); ++i) store_piece(nst, 0, i);
+          if (s == 4) fetch_half(nxt, 1);
+        }
+        if constexpr (!LAST) {                                    // reads first, then four vector instructions behind every MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ff_bf16x8 hp[2][3];
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          hp[sg][p] = __builtin_bit_cast(ff_bf16x8, ff_i32x4{(int)hpw[sg][p][0], (int)hpw[sg][p][1], (int)hpw[sg][p][2], (int)hpw[sg][p][3]});
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase B: GEMM 2: D2[col 32 cb + 8 q + 4 h + t][row r] += W2 . h over this chunk's 32 hidden units; group g = (s, cb),
+      // the next group's fragments requested before this group's MFMAs.  The image's second half is stored behind groups 2 - 5 and
+      // the last two groups' fragments are in registers by then, so the chunk's barrier sits after group 5: groups 6 and 7 cover
+      // it, the first reads of the next iteration and the request for the image after the next ------------------------------------
+      auto w2_frags = [&](ff_bf16x8 (&dst)[3], const int g) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          dst[p] = *reinterpret_cast<const ff_bf16x8 *>(st + w2_off + (g & 3) * 32 * FF_W2ROW + 32 * (g >> 2) + p * FF_W2PLANE);
+      };
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         const int sg = g >> 2, cb = g & 3;
-        if (g < 7) {
-          const int s2 = (g + 1) >> 2, cb2 = (g + 1) & 3;
-#pragma unroll
-          for (int p = 0; p < 3; ++p)
-            wb[(g + 1) & 1][p] = *reinterpret_cast<const ff_bf16x8 *>(st + w2_off + cb2 * 32 * FF_W2ROW + 32 * s2 + p * FF_W2PLANE);
+        if (g < 5) w2_frags(wb[(g + 1) & 1], g + 1);
+        if (g == 5) {
+          w2_frags(wb[0], 6);
+          w2_frags(wc, 7);
         }
-        const ff_bf16x8 a1 = wb[g & 1][0], a2 = wb[g & 1][1], a3 = wb[g & 1][2];
+        if (g == 6) {
+          fetch_half((chunk + 2) % nch, 0);
+          if constexpr (!LAST) {
+            w1_frags(nst, 0);
+            load_bias(nst);
+          }
+        }
+        const ff_bf16x8 a1 = g == 7 ? wc[0] : wb[g & 1][0], a2 = g == 7 ? wc[1] : wb[g & 1][1], a3 = g == 7 ? wc[2] : wb[g & 1][2];
         y_lo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, hp[sg][2], y_lo[cb], 0, 0, 0);
         y_hi[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, hp[sg][0], y_hi[cb], 0, 0, 0);
         y_lo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, hp[sg][0], y_lo[cb], 0, 0, 0);
         y_lo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, hp[sg][1], y_lo[cb], 0, 0, 0);
         y_lo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, hp[sg][1], y_lo[cb], 0, 0, 0);
         y_lo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, hp[sg][0], y_lo[cb], 0, 0, 0);
+        if (g >= 2 && g <= 5) {                                   // two, two, two, one piece
 #pragma unroll
-        for (int i = 2 * g; i < 2 * g + 2 && i < FF_PIECES; ++i)
-          *reinterpret_cast<ff_i32x4 *>(nst + i * (FF_BLOCK * 16) + tid * 16) = gst[i];
+          for (int i = 2 * (g - 2); i < 2 * (g - 2) + 2 && i < FF_HALF; ++i) store_piece(nst, 1, i);
+        }
+        if (g < 5) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        if (g == 5) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        if (g == 6 && !LAST) __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+        if (g >= 2 && g <= 5) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if (g == 5 && !(PCT_FFN_KO & 4)) {
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       cur ^= 1;
-    }
+    };
+    for (int chunk = 0; chunk + 1 < nch; ++chunk) chunk_body(std::false_type{}, chunk);
+    chunk_body(std::true_type{}, nch - 1);
 
     // ---- epilogue: y_*[cb][4 q + t] = y[row r][column 32 cb + 8 q + 4 h + t]; + b2 + residual, LayerNorm, store -----------------
     const unsigned ybytes = (unsigned)((left < 32 ? (left < 0 ? 0 : left) : 32) * ldy * 4);
@@ -299,13 +417,13 @@ int launch_ffn_fused_split(const float *x, long long ldx, const float *w1, const
       return -4;
     attr_dev = dev;
   }
-  const long long pairs = (long long)F * FF_D;                    // element pairs of both matrices
-  hipLaunchKernelGGL(ffn_split_weights_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, stream, w1, w2, F,
+  const long long pairs = (long long)F * FF_D + F / 2;            // element pairs of both matrices and the bias
+  hipLaunchKernelGGL(ffn_split_weights_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, stream, w1, w2, b1, F,
                      static_cast<unsigned short *>(img_ws));
   const long long ntiles = (rows + FF_BM - 1) / FF_BM;
   const unsigned gx = (unsigned)(ntiles < 256 ? ntiles : 256);    // persistent: one workgroup per CU
   hipLaunchKernelGGL(ffn_fused_split_kernel, dim3(gx), dim3(FF_BLOCK), 2 * FF_STAGE, stream, x, ldx,
-                     static_cast<const unsigned short *>(img_ws), F, b1, b2, gamma, beta, eps, rows, out, ldo);
+                     static_cast<const unsigned short *>(img_ws), F, b2, gamma, beta, eps, rows, out, ldo);
   return (int)hipGetLastError();
 }
 
