@@ -491,33 +491,34 @@ def main():
                 "share_of_step": (sum(fwd) / (1e3 * elapsed)) if fwd else None,
             },
         }
-        # second hand-written kernel on the path, MFMA-bound: the FFN's linear1 (+ ReLU) on linear_k128.hip
+        # second hand-written kernel on the path, MFMA-bound: the encoder's whole feed-forward block in one kernel
+        # (ffn_fused_split.hip); the two-kernel path (linear_k128_split + linear_ln_split) when that one does not apply
+        ffn = [rec[1] for rec in launches if rec[0] == "ffn f=1024"]
         ffn1 = [rec[1] for rec in launches if rec[0] == "linear_k128 n=1024 relu"]
-        if ffn1:
-            rows = args.batch * S
-            ms1 = sum(ffn1) / len(ffn1)
-            split = not os.environ.get("PCT_LIN_KERNEL", "").startswith("f")
-            gemm_tf = 2.0 * rows * 128 * 1024 / (ms1 * 1e-3) / 1e12
-            if split:
-                # linear_k128_split.hip: every fp32 product is evaluated as 6 exact bf16 x bf16 partial products, so the
-                # matrix cores execute 6x the GEMM's flops; utilisation is priced on what they execute, against the
-                # dense bf16 MFMA peak
-                tf, peak = 6.0 * gemm_tf, 2500.0
-                kernel = ("pct::linear_k128_split_kernel<bias+ReLU> (encoder FFN linear1: [%d,128] x [1024,128]^T, fp32 "
-                          "operands as exact 3-way bf16 splits, 6 x v_mfma_f32_32x32x16_bf16 per fp32 MFMA-equivalent)" % rows)
-                note = ("achieved = bf16 MFMA flops executed (6 x the GEMM's 2*rows*128*1024) / launch time; peak = dense "
-                        "bf16 MFMA rate; the same GEMM counted once is gemm_fp32_equiv_tflops (the fp32 MFMA peak is "
-                        "157.3); the step's other large GEMM (linear2 + residual + LayerNorm, K = 1024) is linear_ln_split.hip, "
-                        "same arithmetic")
-            else:
-                tf, peak = gemm_tf, 157.3
-                kernel = ("pct::linear_k128_kernel<bias+ReLU> (encoder FFN linear1: [%d,128] x [1024,128]^T, fp32, "
-                          "v_mfma_f32_32x32x2_f32)" % rows)
-                note = "peak = dense fp32 MFMA rate (256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz)"
+        rows = args.batch * S
+        if ffn:
+            msf = sum(ffn) / len(ffn)
+            gemm_tf = 2.0 * 2.0 * rows * 128 * 1024 / (msf * 1e-3) / 1e12        # both products
             out["roofline_mfma"] = {
-                "kernel": kernel, "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                "kernel": "pct::ffn_fused_split_kernel (encoder FFN: LayerNorm(x + W2 relu(W1 x + b1) + b2), x [%d,128], hidden 1024 "
+                          "kept in registers; fp32 operands as exact 3-way bf16 splits, 6 x v_mfma_f32_32x32x16_bf16 per fp32 "
+                          "MFMA-equivalent) + ffn_split_weights_kernel" % rows,
+                "bound": "mfma", "achieved": 6.0 * gemm_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": 6.0 * gemm_tf / 2500.0,
+                "gemm_fp32_equiv_tflops": gemm_tf, "mean_launch_ms": msf, "launches_timed": len(ffn),
+                "share_of_step": sum(ffn) / (1e3 * elapsed),
+                "note": "achieved = bf16 MFMA flops executed (6 x the two GEMMs' 2*rows*128*1024 each) / launch time; peak = "
+                        "dense bf16 MFMA rate at 2.4 GHz (the kernel runs at ~1.85 GHz under the power limit); the same GEMMs "
+                        "counted once are gemm_fp32_equiv_tflops (the fp32 MFMA peak is 157.3)",
+            }
+        elif ffn1:
+            ms1 = sum(ffn1) / len(ffn1)
+            gemm_tf = 2.0 * rows * 128 * 1024 / (ms1 * 1e-3) / 1e12
+            out["roofline_mfma"] = {
+                "kernel": "pct::linear_k128_split_kernel<bias+ReLU> (encoder FFN linear1: [%d,128] x [1024,128]^T)" % rows,
+                "bound": "mfma", "achieved": 6.0 * gemm_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": 6.0 * gemm_tf / 2500.0,
                 "gemm_fp32_equiv_tflops": gemm_tf, "mean_launch_ms": ms1, "launches_timed": len(ffn1),
-                "share_of_step": sum(ffn1) / (1e3 * elapsed), "note": note,
+                "share_of_step": sum(ffn1) / (1e3 * elapsed),
+                "note": "achieved = bf16 MFMA flops executed (6 x the GEMM's) / launch time",
             }
         MFMA_PEAK_TF = 2500.0      # dense bf16 (MI355X_MICROARCH.md); HBM peak as above
         # ---- the per-query dynamic mask head (dec.py:647-719): 10 calls per step on the stride-4 mask features -------------

@@ -28,7 +28,7 @@
 #include <type_traits>
 
 // knock-outs (WRONG RESULTS, timing only): 1 = no image transport inside the chunk loop, 2 = no bias / ReLU / split arithmetic,
-// 4 = no barrier per chunk, 16 / 32 = of the transport only the LDS stores / only the loads
+// 4 = no barrier per chunk, 16 / 32 = of the transport only the LDS stores / only the loads, 8 = no residual loads, 64 = no y stores
 #ifndef PCT_FFN_KO
 #define PCT_FFN_KO 0
 #endif
@@ -36,7 +36,36 @@
 #error "PCT_FFN_KO gives wrong results: add -DPCT_EXPERIMENT_BUILD"
 #endif
 
+// PCT_FFN_STAMPS (experiment builds): s_memtime at the phase boundaries of every chunk, sums per workgroup in pct_ffn_stamps
+#ifndef PCT_FFN_SPREAD
+#define PCT_FFN_SPREAD 1      /* fragment reads spread between the MFMAs of a group instead of issued together at its start */
+#endif
+#ifndef PCT_FFN_STAMPS
+#define PCT_FFN_STAMPS 0
+#endif
+#if PCT_FFN_STAMPS && !defined(PCT_EXPERIMENT_BUILD)
+#error "PCT_FFN_STAMPS perturbs the kernel: add -DPCT_EXPERIMENT_BUILD"
+#endif
+
 namespace pct {
+
+#if PCT_FFN_STAMPS
+__device__ unsigned long long ffn_stamps[256 * 8];
+__device__ __forceinline__ unsigned long long ff_now()
+{
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define FF_STAMP(slot)                                   \
+  do {                                                   \
+    const unsigned long long now_ = ff_now();            \
+    acc_t[slot] += now_ - last_t;                        \
+    last_t = now_;                                       \
+  } while (0)
+#else
+#define FF_STAMP(slot)
+#endif
 
 typedef float ff_f32x16 __attribute__((ext_vector_type(16)));
 typedef float ff_f32x4 __attribute__((ext_vector_type(4)));
@@ -57,6 +86,7 @@ constexpr int FF_W2OFF = 3 * FF_W1PLANE;          // 26 112
 constexpr int FF_STAGE = 57344;                   // 26 112 + 30 720 = 56 832, padded to 256 threads x 14 x 16 B
 constexpr int FF_PIECES = FF_STAGE / (FF_BLOCK * 16);   // 14
 constexpr int FF_HALF = FF_PIECES / 2;                  // 7
+constexpr int FF_LDS = 2 * FF_STAGE + 3 * FF_D * 4;     // two stages, then b2, gamma, beta
 constexpr int FF_B1OFF = 56832;                         // the chunk's 32 biases, in the padding
 
 __device__ __forceinline__ void ff_split(const float x, const float y, unsigned &p1, unsigned &p2, unsigned &p3)
@@ -130,26 +160,30 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
   const int r = lane & 31, h = lane >> 5;
   const long long ntiles = (M + FF_BM - 1) / FF_BM;
   const int nch = F / FF_CH;
+#if PCT_FFN_STAMPS
+  unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_t = ff_now();
+#endif
 
   const auto img_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(img), 0, (int)((long long)nch * FF_STAGE),
                                                           0x00020000);
-  // an image travels to LDS through registers in two halves of seven 16-byte pieces per thread
-  ff_i32x4 gst[FF_HALF];
+  // An image travels to LDS through registers, 14 pieces of 16 bytes per thread, ONE load and one store per MFMA group of six: the
+  // CU's vector-memory path takes a 1 KiB wave-instruction per ~16 cycles, so the four waves' loads issued together in bursts of
+  // seven backed up into the issuing waves (stamps: ~50 cycles per load, 700 per chunk).  Window position p = 0 .. 13 is piece
+  // ORD[p] (the W2 / bias part first: see the tile seam below), stored six groups after it was requested, slot p % 7.
+  ff_i32x4 gst[7];
   bool transport = true;
-  auto fetch_half = [&](const int chunk, const int half) {
-    if ((PCT_FFN_KO & 1) && !transport) return;
-    if ((PCT_FFN_KO & 16) && !transport) return;                  // stores only
-#pragma unroll
-    for (int i = 0; i < FF_HALF; ++i)
-      gst[i] = __builtin_amdgcn_raw_buffer_load_b128(img_rsrc, tid * 16, chunk * FF_STAGE + (half * FF_HALF + i) * (FF_BLOCK * 16), 0);
+  auto t_piece = [](const int p) { return p < 7 ? p + 7 : p - 7; };
+  auto t_load = [&](const int p, const int image) {
+    if ((PCT_FFN_KO & (1 | 16)) && !transport) return;
+    gst[p % 7] = __builtin_amdgcn_raw_buffer_load_b128(img_rsrc, tid * 16, image * FF_STAGE + t_piece(p) * (FF_BLOCK * 16), 0);
   };
-  auto store_piece = [&](unsigned char *st, const int half, const int i) {
+  auto t_store = [&](const int p, unsigned char *stage) {
     if ((PCT_FFN_KO & 1) && !transport) return;
-    if ((PCT_FFN_KO & 32) && !transport) {                        // loads only
-      asm volatile("" ::"v"(gst[i]));
+    if ((PCT_FFN_KO & 32) && !transport) {
+      asm volatile("" ::"v"(gst[p % 7]));
       return;
     }
-    *reinterpret_cast<ff_i32x4 *>(st + (half * FF_HALF + i) * (FF_BLOCK * 16) + tid * 16) = gst[i];
+    *reinterpret_cast<ff_i32x4 *>(stage + t_piece(p) * (FF_BLOCK * 16) + tid * 16) = gst[p % 7];
   };
 
   // fragment addresses inside a stage: W1 (A operand of GEMM 1): hidden row r, k = 16 s + 8 h ..; W2 (A operand of GEMM 2):
@@ -157,37 +191,63 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
   const int w1_off = r * FF_W1ROW + 16 * h;                       // + 32 s, + plane
   const int w2_off = FF_W2OFF + r * FF_W2ROW + 16 * h;            // + cb * 32 rows, + 32 s, + plane
 
-  // stage 1 <- the last image (W1 of chunk 0), stage 0 <- image 0
+  // stage 1 <- the last image (W1 of chunk 0), stage 0 <- image 0; then what the groups before "iteration 0" would have done for
+  // image 1 (into stage 1: its W2 part only, the W1 part there is still needed): positions 0 and 1 stored, 2 .. 7 requested
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    fetch_half(nch - 1, half);
+  for (int p0 = 0; p0 < 14; p0 += 7) {
 #pragma unroll
-    for (int i = 0; i < FF_HALF; ++i) store_piece(ff_smem + FF_STAGE, half, i);
-    fetch_half(0, half);
+    for (int p = p0; p < p0 + 7; ++p) t_load(p, nch - 1);
 #pragma unroll
-    for (int i = 0; i < FF_HALF; ++i) store_piece(ff_smem, half, i);
+    for (int p = p0; p < p0 + 7; ++p) t_store(p, ff_smem + FF_STAGE);
+#pragma unroll
+    for (int p = p0; p < p0 + 7; ++p) t_load(p, 0);
+#pragma unroll
+    for (int p = p0; p < p0 + 7; ++p) t_store(p, ff_smem);
   }
+  if (tid < FF_D) {                                               // b2, gamma, beta behind the stages
+    float *par = reinterpret_cast<float *>(ff_smem + 2 * FF_STAGE);
+    par[tid] = b2 ? b2[tid] : 0.f;
+    par[FF_D + tid] = gamma[tid];
+    par[2 * FF_D + tid] = beta[tid];
+  }
+  t_load(0, 1 % nch);
+  t_load(1, 1 % nch);
+  t_store(0, ff_smem + FF_STAGE);
+  t_store(1, ff_smem + FF_STAGE);
+#pragma unroll
+  for (int p = 2; p < 8; ++p) t_load(p, 1 % nch);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   int cur = 0;                                                    // stage holding the image of the chunk about to be used
-  fetch_half(1 % nch, 0);                                         // iteration 0 stores image 1
   transport = false;
+  FF_STAMP(0);
+
+  // a tile's rows of x are requested one tile ahead (under the last chunk of the tile before, when the fragments of the current
+  // rows are no longer needed): lane (r, h) takes k = 16 s + 8 h .. + 7 of row r, s = 0 .. 7
+  ff_i32x4 xraw[16];
+  auto x_request = [&](const long long tile) {
+    const long long row0 = tile * FF_BM + 32 * wave;
+    const long long left = M - row0;
+    const unsigned xbytes = (unsigned)((left < 32 ? (left < 0 ? 0 : left) : 32) * ldx * 4);      // past the end: zeros
+    const auto xq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X + (left > 0 ? row0 : 0) * ldx), 0, (int)xbytes, 0x00020000);
+    const int xoff = (int)((r * ldx + 8 * h) * 4);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      xraw[2 * s] = __builtin_amdgcn_raw_buffer_load_b128(xq, xoff, s * 64, 0);
+      xraw[2 * s + 1] = __builtin_amdgcn_raw_buffer_load_b128(xq, xoff, s * 64 + 16, 0);
+    }
+  };
+  x_request(blockIdx.x);
 
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // ---- this wave's 32 rows of x as GEMM 1's B fragments: lane (r, h) takes k = 16 s + 8 h .. + 7 of row r ----------------
+    // ---- this wave's 32 rows of x as GEMM 1's B fragments ---------------------------------------------------------------------
     const long long row0 = tile * FF_BM + 32 * wave;
     const long long left = M - row0;
     const unsigned xbytes = (unsigned)((left < 32 ? (left < 0 ? 0 : left) : 32) * ldx * 4);
     const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X + row0 * ldx), 0, (int)xbytes, 0x00020000);
     ff_bf16x8 xp[8][3];
-    {
-      const int xoff = (int)((r * ldx + 8 * h) * 4);
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const ff_f32x4 a = __builtin_bit_cast(ff_f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff, s * 64, 0));
-        const ff_f32x4 b = __builtin_bit_cast(ff_f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff, s * 64 + 16, 0));
-        ff_split8(a, b, xp[s]);
-      }
-    }
+    for (int s = 0; s < 8; ++s) ff_split8(__builtin_bit_cast(ff_f32x4, xraw[2 * s]), __builtin_bit_cast(ff_f32x4, xraw[2 * s + 1]), xp[s]);
+    FF_STAMP(1);
     ff_f32x16 y_hi[4], y_lo[4];                                   // D2[col block][cols 32][rows 32]
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
@@ -237,12 +297,13 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
     };
     w1_frags(ff_smem + cur * FF_STAGE, 0);
     load_bias(ff_smem + cur * FF_STAGE);
+    FF_STAMP(2);
 
     auto chunk_body = [&](auto last_tag, const int chunk) {
       constexpr bool LAST = decltype(last_tag)::value;
       const unsigned char *st = ff_smem + cur * FF_STAGE;         // image `chunk`: W2 and b1 of this chunk, W1 of the next
       unsigned char *nst = ff_smem + (cur ^ 1) * FF_STAGE;        // nobody reads it since the previous barrier: image chunk + 1
-      const int nxt = LAST ? 0 : chunk + 1;
+      const int nxt = LAST ? 0 : chunk + 1, nxt2 = (chunk + 2) % nch;
       // this chunk's hidden accumulators move to the vector side; the same registers then take the next chunk's product
       const ff_f32x16 c_hi = h_hi, c_lo = h_lo;
       if constexpr (!LAST) {
@@ -250,11 +311,26 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
         for (int j = 0; j < 16; ++j) h_hi[j] = h_lo[j] = 0.f;
       }
       __builtin_amdgcn_sched_barrier(0);
-      // ---- phase A: GEMM 1 of chunk + 1 under bias, ReLU, split of this chunk: step s finishes value pair s of the B fragments of
-      // GEMM 2 (k-step sg = s / 4, word w = s % 4: accumulator quartet q = 2 sg + w / 2, elements 2 (w % 2) and + 1); the first
-      // half of image chunk + 1 (requested a quarter of an iteration ago) is stored in steps 2 - 4, the second half requested -----
+      // ---- phase A: GEMM 1 of chunk + 1 under bias, ReLU, split of this chunk: value pair m of the B fragments of GEMM 2 is k-step
+      // sg = m / 4, word w = m % 4 (accumulator quartet q = 2 sg + w / 2, elements 2 (w % 2) and + 1); pairs 0 - 3 (k-step 0) behind
+      // the odd steps here, pairs 4 - 7 (k-step 1, first used by group 4) behind groups 0 - 3 of phase B; image chunk + 1: positions
+      // 2 .. 9 stored, 8 .. 13 requested ------------------------------------------------------------------------------------------
       unsigned hpw[2][3][4];
       ff_bf16x8 wb[2][3], wc[3];
+      auto valu_slice = [&](const int m) {
+        const int sg = m >> 2, w = m & 3, q = 2 * sg + (w >> 1), t0 = 2 * (w & 1), j0 = 4 * q + t0;
+        const float v0 = fmaxf((c_hi[j0] + c_lo[j0]) + bq[q][t0], 0.f);
+        const float v1 = fmaxf((c_hi[j0 + 1] + c_lo[j0 + 1]) + bq[q][t0 + 1], 0.f);
+        if (PCT_FFN_KO & 2) {
+          hpw[sg][0][w] = __float_as_uint(c_hi[j0]);
+          hpw[sg][1][w] = __float_as_uint(c_lo[j0]);
+          hpw[sg][2][w] = __float_as_uint(c_hi[j0 + 1]) ^ __float_as_uint(c_lo[j0 + 1]);
+        } else
+          ff_split(v0, v1, hpw[sg][0][w], hpw[sg][1][w], hpw[sg][2][w]);
+      };
+      auto h_frag = [&](const int sg, const int p) {
+        return __builtin_bit_cast(ff_bf16x8, ff_i32x4{(int)hpw[sg][p][0], (int)hpw[sg][p][1], (int)hpw[sg][p][2], (int)hpw[sg][p][3]});
+      };
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         if constexpr (!LAST) {
@@ -265,43 +341,29 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
 #pragma unroll
           for (int p = 0; p < 3; ++p) wb[0][p] = *reinterpret_cast<const ff_bf16x8 *>(st + w2_off + p * FF_W2PLANE);
         }
-        {
-          const int sg = s >> 2, w = s & 3, q = 2 * sg + (w >> 1), t0 = 2 * (w & 1), j0 = 4 * q + t0;
-          const float v0 = fmaxf((c_hi[j0] + c_lo[j0]) + bq[q][t0], 0.f);
-          const float v1 = fmaxf((c_hi[j0 + 1] + c_lo[j0 + 1]) + bq[q][t0 + 1], 0.f);
-          if (PCT_FFN_KO & 2) {
-            hpw[sg][0][w] = __float_as_uint(c_hi[j0]);
-            hpw[sg][1][w] = __float_as_uint(c_lo[j0]);
-            hpw[sg][2][w] = __float_as_uint(c_hi[j0 + 1]) ^ __float_as_uint(c_lo[j0 + 1]);
-          } else
-            ff_split(v0, v1, hpw[sg][0][w], hpw[sg][1][w], hpw[sg][2][w]);
-        }
-        if (s >= 2 && s <= 4) {                                   // three, two, two pieces
-#pragma unroll
-          for (int i = (s == 2 ? 0 : s == 3 ? 3 : 5); i < (s == 2 ? 3 : s == 3 ? 5 : 7); ++i) store_piece(nst, 0, i);
-          if (s == 4) fetch_half(nxt, 1);
-        }
-        if constexpr (!LAST) {                                    // reads first, then four vector instructions behind every MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        if (s & 1) valu_slice(s >> 1);
+        t_store(s + 2, nst);
+        if (s <= 5) t_load(s + 8, nxt);
+        if constexpr (!LAST) {                                    // reads first; vector instructions, the load and the store between MFMAs
+          if (!PCT_FFN_SPREAD) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            if (s & 1) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            if (PCT_FFN_SPREAD && !(i & 1)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i == 1 && s <= 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (i == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      ff_bf16x8 hp[2][3];
-#pragma unroll
-      for (int sg = 0; sg < 2; ++sg)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          hp[sg][p] = __builtin_bit_cast(ff_bf16x8, ff_i32x4{(int)hpw[sg][p][0], (int)hpw[sg][p][1], (int)hpw[sg][p][2], (int)hpw[sg][p][3]});
+      FF_STAMP(3);
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase B: GEMM 2: D2[col 32 cb + 8 q + 4 h + t][row r] += W2 . h over this chunk's 32 hidden units; group g = (s, cb),
-      // the next group's fragments requested before this group's MFMAs.  The image's second half is stored behind groups 2 - 5 and
-      // the last two groups' fragments are in registers by then, so the chunk's barrier sits after group 5: groups 6 and 7 cover
-      // it, the first reads of the next iteration and the request for the image after the next ------------------------------------
+      // the next group's fragments requested before this group's MFMAs.  Image chunk + 1 is complete behind group 3 and the last two
+      // groups' fragments are in registers before group 6, so the chunk's barrier sits after group 5: groups 6 and 7 cover it, the
+      // first reads of the next iteration and the first two stores of image chunk + 2 into the stage just read (its W2 part: at a
+      // tile seam the W1 part is still needed by the next tile's first product); image chunk + 2 is requested from group 0 on -------
       auto w2_frags = [&](ff_bf16x8 (&dst)[3], const int g) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
@@ -315,46 +377,52 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
           w2_frags(wb[0], 6);
           w2_frags(wc, 7);
         }
+        if (g < 4) valu_slice(4 + g);
+        t_load(g, nxt2);
+        if (g < 4) t_store(10 + g, nst);
+        if (g >= 6) t_store(g - 6, const_cast<unsigned char *>(st));   // behind the barrier: this stage is free, image chunk + 2
         if (g == 6) {
-          fetch_half((chunk + 2) % nch, 0);
           if constexpr (!LAST) {
             w1_frags(nst, 0);
             load_bias(nst);
           }
         }
         const ff_bf16x8 a1 = g == 7 ? wc[0] : wb[g & 1][0], a2 = g == 7 ? wc[1] : wb[g & 1][1], a3 = g == 7 ? wc[2] : wb[g & 1][2];
-        y_lo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, hp[sg][2], y_lo[cb], 0, 0, 0);
-        y_hi[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, hp[sg][0], y_hi[cb], 0, 0, 0);
-        y_lo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, hp[sg][0], y_lo[cb], 0, 0, 0);
-        y_lo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, hp[sg][1], y_lo[cb], 0, 0, 0);
-        y_lo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, hp[sg][1], y_lo[cb], 0, 0, 0);
-        y_lo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, hp[sg][0], y_lo[cb], 0, 0, 0);
-        if (g >= 2 && g <= 5) {                                   // two, two, two, one piece
+        y_lo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, h_frag(sg, 2), y_lo[cb], 0, 0, 0);
+        y_hi[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, h_frag(sg, 0), y_hi[cb], 0, 0, 0);
+        y_lo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, h_frag(sg, 0), y_lo[cb], 0, 0, 0);
+        y_lo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, h_frag(sg, 1), y_lo[cb], 0, 0, 0);
+        y_lo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, h_frag(sg, 1), y_lo[cb], 0, 0, 0);
+        y_lo[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, h_frag(sg, 0), y_lo[cb], 0, 0, 0);
+        if (g < 5 && !PCT_FFN_SPREAD) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        if (g == 5 && !PCT_FFN_SPREAD) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        if (g == 6 && !LAST && !PCT_FFN_SPREAD) __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
 #pragma unroll
-          for (int i = 2 * (g - 2); i < 2 * (g - 2) + 2 && i < FF_HALF; ++i) store_piece(nst, 1, i);
-        }
-        if (g < 5) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-        if (g == 5) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-        if (g == 6 && !LAST) __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
-        if (g >= 2 && g <= 5) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        for (int i = 0; i < 6; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (g < 4) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          if (PCT_FFN_SPREAD) {                                   // fragment reads one (two, group 5 and 6) per MFMA, not in a burst
+            if (g < 5 && !(i & 1)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (g == 5) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (g == 6 && !LAST) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (g == 6 && !LAST && i == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        } else {
-          __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+          if (i == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          if (i == 3 && (g < 4 || g >= 6)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (g == 5 && !(PCT_FFN_KO & 4)) {
+          FF_STAMP(4);
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
+          FF_STAMP(5);
         }
       }
+      FF_STAMP(6);
       cur ^= 1;
     };
     for (int chunk = 0; chunk + 1 < nch; ++chunk) chunk_body(std::false_type{}, chunk);
+    x_request(tile + gridDim.x);
     chunk_body(std::true_type{}, nch - 1);
 
     // ---- epilogue: y_*[cb][4 q + t] = y[row r][column 32 cb + 8 q + 4 h + t]; + b2 + residual, LayerNorm, store -----------------
@@ -366,8 +434,9 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c0 = 32 * cb + 8 * q + 4 * h;
-        const ff_f32x4 res = __builtin_bit_cast(ff_f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)((r * ldx + c0) * 4), 0, 0));
-        const ff_f32x4 bb = b2 ? *reinterpret_cast<const ff_f32x4 *>(b2 + c0) : ff_f32x4{0.f, 0.f, 0.f, 0.f};
+        const ff_f32x4 res = (PCT_FFN_KO & 8) ? ff_f32x4{0.f, 0.f, 0.f, 0.f}
+                                              : __builtin_bit_cast(ff_f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)((r * ldx + c0) * 4), 0, 0));
+        const ff_f32x4 bb = *reinterpret_cast<const ff_f32x4 *>(ff_smem + 2 * FF_STAGE + c0 * 4);
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[16 * cb + 4 * q + t] = ((y_hi[cb][4 * q + t] + y_lo[cb][4 * q + t]) + bb[t]) + res[t];
       }
@@ -389,14 +458,22 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c0 = 32 * cb + 8 * q + 4 * h;
-        const ff_f32x4 gq = *reinterpret_cast<const ff_f32x4 *>(gamma + c0);
-        const ff_f32x4 eq = *reinterpret_cast<const ff_f32x4 *>(beta + c0);
+        const ff_f32x4 gq = *reinterpret_cast<const ff_f32x4 *>(ff_smem + 2 * FF_STAGE + (FF_D + c0) * 4);
+        const ff_f32x4 eq = *reinterpret_cast<const ff_f32x4 *>(ff_smem + 2 * FF_STAGE + (2 * FF_D + c0) * 4);
         ff_f32x4 o;
 #pragma unroll
         for (int t = 0; t < 4; ++t) o[t] = v[16 * cb + 4 * q + t] * rstd * gq[t] + eq[t];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ff_i32x4, o), yr, (int)((r * ldy + c0) * 4), 0, 0);
+        if (PCT_FFN_KO & 64)
+          asm volatile("" ::"v"(o));
+        else
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ff_i32x4, o), yr, (int)((r * ldy + c0) * 4), 0, 0);
       }
+    FF_STAMP(7);
   }
+#if PCT_FFN_STAMPS
+  if (tid == 0 && blockIdx.x < 256)
+    for (int i = 0; i < 8; ++i) ffn_stamps[blockIdx.x * 8 + i] = acc_t[i];
+#endif
 }
 
 // img_ws: (F / 32) * 57 344 bytes, 16-byte aligned, refilled on every call.  -4: geometry not covered.
@@ -413,7 +490,7 @@ int launch_ffn_fused_split(const float *x, long long ldx, const float *w1, const
   if (hipGetDevice(&dev) != hipSuccess) return -4;
   if (attr_dev != dev) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ffn_fused_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            2 * FF_STAGE) != hipSuccess)
+                            FF_LDS) != hipSuccess)
       return -4;
     attr_dev = dev;
   }
@@ -422,9 +499,16 @@ int launch_ffn_fused_split(const float *x, long long ldx, const float *w1, const
                      static_cast<unsigned short *>(img_ws));
   const long long ntiles = (rows + FF_BM - 1) / FF_BM;
   const unsigned gx = (unsigned)(ntiles < 256 ? ntiles : 256);    // persistent: one workgroup per CU
-  hipLaunchKernelGGL(ffn_fused_split_kernel, dim3(gx), dim3(FF_BLOCK), 2 * FF_STAGE, stream, x, ldx,
+  hipLaunchKernelGGL(ffn_fused_split_kernel, dim3(gx), dim3(FF_BLOCK), FF_LDS, stream, x, ldx,
                      static_cast<const unsigned short *>(img_ws), F, b2, gamma, beta, eps, rows, out, ldo);
   return (int)hipGetLastError();
 }
+
+#if PCT_FFN_STAMPS
+extern "C" __attribute__((visibility("default"))) int pct_ffn_stamps_read(unsigned long long *host_out)
+{
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ffn_stamps), sizeof(unsigned long long) * 256 * 8);
+}
+#endif
 
 }  // namespace pct
