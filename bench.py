@@ -294,6 +294,27 @@ def traffic_from_profile(args):
     return None
 
 
+def issue_from_profile(args, prefix):
+    """Issue-side SQ counters of one kernel family from the committed PMC passes over this script (tools/pmc_bench_issue.sh ->
+    profiles/r04_bench_issue.json): the share of SIMD cycles the matrix pipe is busy, a vector instruction is issuing, an LDS
+    instruction is issuing.  The unit a kernel keeps busiest is the bound it is nearest to; only for the judged workload."""
+    if not (args.batch == 128 and args.levels == 4 and args.image == 512 and args.loc_dist == "M"):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_bench_issue.json")) as f:
+            t = json.load(f)
+        recs = [v for k, v in t["kernels"].items() if k.startswith(prefix)]
+        if not recs:
+            return None
+        n = sum(r["launches"] for r in recs)
+        out = {k: sum(r[k] * r["launches"] for r in recs) / n for k in ("mfma_busy", "valu_issue", "lds_issue", "wait_any")}
+        out["nearest_bound"] = max(("mfma_busy", "valu_issue", "lds_issue"), key=lambda k: out[k])
+        out["source"] = "profiles/r04_bench_issue.json"
+        return out
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` (the
     reference's launch, README.md:30-33, in its current spelling) and return its exit code.  Nothing in this process
@@ -489,6 +510,7 @@ def main():
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic_from_profile(args),
                 "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_ms, "launches_timed": len(fwd),
                 "share_of_step": (sum(fwd) / (1e3 * elapsed)) if fwd else None,
+                "issue": issue_from_profile(args, "pct::msda_forward_col_kernel"),
             },
         }
         # second hand-written kernel on the path, MFMA-bound: the encoder's whole feed-forward block in one kernel
@@ -505,7 +527,7 @@ def main():
                           "MFMA-equivalent) + ffn_split_weights_kernel" % rows,
                 "bound": "mfma", "achieved": 6.0 * gemm_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": 6.0 * gemm_tf / 2500.0,
                 "gemm_fp32_equiv_tflops": gemm_tf, "mean_launch_ms": msf, "launches_timed": len(ffn),
-                "share_of_step": sum(ffn) / (1e3 * elapsed),
+                "share_of_step": sum(ffn) / (1e3 * elapsed), "issue": issue_from_profile(args, "pct::ffn_fused_split_kernel"),
                 "note": "achieved = bf16 MFMA flops executed (6 x the two GEMMs' 2*rows*128*1024 each) / launch time; peak = "
                         "dense bf16 MFMA rate at 2.4 GHz (the kernel runs at ~1.85 GHz under the power limit); the same GEMMs "
                         "counted once are gemm_fp32_equiv_tflops (the fp32 MFMA peak is 157.3)",
@@ -546,6 +568,7 @@ def main():
                 "useful_TFLOPs": useful / (ms_mh * 1e-3) / 1e12, "executed_mfma_TFLOPs": executed / (ms_mh * 1e-3) / 1e12,
                 "peak_TFLOPs": MFMA_PEAK_TF, "algorithmic_bytes_per_call": alg, "mean_call_ms": ms_mh,
                 "calls_timed": len(mh), "share_of_step": sum(mh) / (1e3 * elapsed), "note": alg_note,
+                "issue": issue_from_profile(args, "pct::dmh_fused_kernel"),
             }
         # ---- masked cross-attention (attention.py:271-387) at the decoder's finest level (most keys) --------------------------
         xa = {}
@@ -569,6 +592,7 @@ def main():
                 "algorithmic_bytes_per_call": alg, "mean_call_ms": ms_a, "calls_timed": len(tl),
                 "all_levels_ms": {"%s S=%d" % k: sum(v) / len(v) for k, v in sorted(xa.items())},
                 "share_of_step": sum(sum(v) for v in xa.values()) / (1e3 * elapsed),
+                "issue": issue_from_profile(args, "pct::cross_attention_kernel"),
                 "note": "algorithmic bytes: K-content, K-position, V, the query halves and the output once (bf16), mask bytes once",
             }
         if not args.no_cpu_baseline and world == 1:
