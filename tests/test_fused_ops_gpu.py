@@ -649,7 +649,7 @@ def test_conv1x1_groupnorm_tokens_equals_the_module_chain(N, K, H, W):
     assert err <= 2e-5, err
 
 
-@pytest.mark.parametrize("rows,F", [(128, 1024), (4000, 1024), (37, 64), (257, 2048)])
+@pytest.mark.parametrize("rows,F", [(128, 1024), (4000, 1024), (37, 64), (257, 2048), (129, 32), (1000, 96), (70001, 1024)])
 def test_fused_ffn_is_as_accurate_as_fp32(rows, F):
     """The encoder layer's FFN in one kernel (csrc/ffn_fused_split.hip: the hidden activations stay in registers between the two
     split-bf16 products) against fp64 and against the fp32 module chain norm2(x + linear2(relu(linear1(x))))
@@ -674,3 +674,37 @@ def test_fused_ffn_is_as_accurate_as_fp32(rows, F):
     err32 = float((chain.double() - ref).abs().max())
     assert torch.isfinite(got).all() and got.shape == x.shape
     assert err <= max(2.0 * err32, 5e-6), (err, err32)
+
+
+def test_fused_ffn_strided_rows_no_bias_and_repeat_calls():
+    """Rows that are a column slice of a wider tensor (row stride 160 floats), linear2 without a bias, and the same workspace
+    reused by calls with different weights (the weight images are refilled per call); the persistent loop over several tiles
+    per workgroup against the two-kernel path."""
+    torch.manual_seed(5)
+    norm = torch.nn.LayerNorm(128).cuda()
+    wide = torch.randn(40000, 160, device="cuda")
+    x = wide[:, 16:144]
+    assert x.stride(0) == 160 and x.data_ptr() % 16 == 0
+    with torch.no_grad():
+        for seed in (1, 2):
+            torch.manual_seed(seed)
+            l1, l2 = torch.nn.Linear(128, 256).cuda(), torch.nn.Linear(256, 128, bias=seed == 1).cuda()
+            assert fused_ops.ffn_layer_norm_supported(x, l1, l2, norm)
+            got = fused_ops.ffn_layer_norm(x, l1, l2, norm)
+            two = fused_ops.linear_layer_norm(fused_ops.linear(x.contiguous(), l1, relu=True), l2, x.contiguous(), norm)
+            ref = torch.nn.functional.layer_norm(
+                x.double() + torch.relu(x.double() @ l1.weight.double().t() + l1.bias.double()) @ l2.weight.double().t()
+                + (l2.bias.double() if l2.bias is not None else 0.0), (128,), norm.weight.double(), norm.bias.double(), norm.eps)
+            assert float((got.double() - ref).abs().max()) <= 5e-6
+            assert float((got - two).abs().max()) <= 5e-6
+    assert float((wide[:, :16] - wide[:, :16]).abs().max()) == 0.0
+
+
+def test_fused_ffn_refuses_what_it_does_not_cover():
+    l1, l2, norm = torch.nn.Linear(128, 1000).cuda(), torch.nn.Linear(1000, 128).cuda(), torch.nn.LayerNorm(128).cuda()
+    x = torch.randn(64, 128, device="cuda")
+    with torch.no_grad():
+        assert not fused_ops.ffn_layer_norm_supported(x, l1, l2, norm)                      # hidden % 32
+        assert not fused_ops.ffn_layer_norm_supported(x.half(), l1, l2, norm)
+    l1b = torch.nn.Linear(128, 1024).cuda()
+    assert not fused_ops.ffn_layer_norm_supported(x.requires_grad_(True), l1b, torch.nn.Linear(1024, 128).cuda(), norm)   # autograd
