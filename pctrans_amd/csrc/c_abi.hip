@@ -42,6 +42,7 @@ int prepare_win_queue_device();
 int prepare_msda_backward_col_device();
 const char *msda_forward_col_build_flags();
 const char *msda_backward_col_build_flags();
+const char *ffn_fused_build_flags();
 int launch_msda_forward_planes(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int, int,
                                int, int, int, void *, hipStream_t, const float *, long long);
 int launch_ffn_fused_split(const float *, long long, const float *, const float *, const float *, const float *, const float *,
@@ -509,8 +510,8 @@ const char *pct_build_info(void)
 #else
     const char *exp = "0";
 #endif
-    snprintf(buf, sizeof(buf), "experiment=%s; target=gfx950; %s; %s", exp, pct::msda_forward_col_build_flags(),
-             pct::msda_backward_col_build_flags());
+    snprintf(buf, sizeof(buf), "experiment=%s; target=gfx950; %s; %s; %s", exp, pct::msda_forward_col_build_flags(),
+             pct::msda_backward_col_build_flags(), pct::ffn_fused_build_flags());
     return true;
   }();
   (void)once;

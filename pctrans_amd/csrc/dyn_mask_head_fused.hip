@@ -24,6 +24,9 @@
 
 namespace pct {
 
+#ifndef PCT_DMH_WGS
+#define PCT_DMH_WGS 2          /* workgroups per CU the register budget is set for (3: 168 registers, ~30 spilled: 0.36 -> 0.53 ms at batch 64) */
+#endif
 constexpr int FZ_W = 128;              // feature-map width this kernel is built for (8 tiles of 16 pixels per row)
 constexpr int FZ_BAND = 8;             // rows per workgroup
 constexpr int FZ_TILES = 20;           // per wave: 2 x 8 own tiles + 4 halo tiles
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(64) void dmh_prepare_kernel(const float *__restrict
 
 // up [N, Q, 2H, 256] bf16, amask [N, Q, (H/SC) * (128/SC)] bytes
 template <bool REL, int SC>
-__global__ __launch_bounds__(256, 2) void dmh_fused_kernel(const float *__restrict__ feat,
+__global__ __launch_bounds__(256, PCT_DMH_WGS) void dmh_fused_kernel(const float *__restrict__ feat,
                                                            const unsigned *__restrict__ ws, const int Q, const int H,
                                                            const int stride, __bf16 *__restrict__ up,
                                                            unsigned char *__restrict__ amask)

@@ -476,6 +476,10 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
 #endif
 }
 
+#define PCT_FF_STR2(x) #x
+#define PCT_FF_STR(x) PCT_FF_STR2(x)
+const char *ffn_fused_build_flags() { return "ffn: KO=" PCT_FF_STR(PCT_FFN_KO) " STAMPS=" PCT_FF_STR(PCT_FFN_STAMPS) " SPREAD=" PCT_FF_STR(PCT_FFN_SPREAD); }
+
 // img_ws: (F / 32) * 57 344 bytes, 16-byte aligned, refilled on every call.  -4: geometry not covered.
 int launch_ffn_fused_split(const float *x, long long ldx, const float *w1, const float *b1, const float *w2, const float *b2,
                            const float *gamma, const float *beta, float eps, int F, long long rows, void *img_ws, float *out,
