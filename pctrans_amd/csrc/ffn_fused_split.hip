@@ -221,22 +221,22 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
   transport = false;
   FF_STAMP(0);
 
-  // a tile's rows of x are requested one tile ahead (under the last chunk of the tile before, when the fragments of the current
-  // rows are no longer needed): lane (r, h) takes k = 16 s + 8 h .. + 7 of row r, s = 0 .. 7
+  // a tile's rows of x are requested one tile ahead (under GEMM 2 of the last chunk of the tile before, when the fragments of the
+  // current rows are no longer needed; a row-strided load touches 32 lines: 16 of them back to back cost 3 k cycles): lane (r, h) takes k = 16 s + 8 h .. + 7 of row r, s = 0 .. 7
   ff_i32x4 xraw[16];
-  auto x_request = [&](const long long tile) {
+  auto x_request = [&](const long long tile, const int s0, const int s1) {      // k-steps s0 .. s1 - 1
     const long long row0 = tile * FF_BM + 32 * wave;
     const long long left = M - row0;
     const unsigned xbytes = (unsigned)((left < 32 ? (left < 0 ? 0 : left) : 32) * ldx * 4);      // past the end: zeros
     const auto xq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X + (left > 0 ? row0 : 0) * ldx), 0, (int)xbytes, 0x00020000);
     const int xoff = (int)((r * ldx + 8 * h) * 4);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = s0; s < s1; ++s) {
       xraw[2 * s] = __builtin_amdgcn_raw_buffer_load_b128(xq, xoff, s * 64, 0);
       xraw[2 * s + 1] = __builtin_amdgcn_raw_buffer_load_b128(xq, xoff, s * 64 + 16, 0);
     }
   };
-  x_request(blockIdx.x);
+  x_request(blockIdx.x, 0, 8);
 
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // ---- this wave's 32 rows of x as GEMM 1's B fragments ---------------------------------------------------------------------
@@ -379,6 +379,7 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
         }
         if (g < 4) valu_slice(4 + g);
         t_load(g, nxt2);
+        if constexpr (LAST) x_request(tile + gridDim.x, g, g + 1);     // the next tile's rows, two row-strided loads per group
         if (g < 4) t_store(10 + g, nst);
         if (g >= 6) t_store(g - 6, const_cast<unsigned char *>(st));   // behind the barrier: this stage is free, image chunk + 2
         if (g == 6) {
@@ -422,7 +423,6 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
       cur ^= 1;
     };
     for (int chunk = 0; chunk + 1 < nch; ++chunk) chunk_body(std::false_type{}, chunk);
-    x_request(tile + gridDim.x);
     chunk_body(std::true_type{}, nch - 1);
 
     // ---- epilogue: y_*[cb][4 q + t] = y[row r][column 32 cb + 8 q + 4 h + t]; + b2 + residual, LayerNorm, store -----------------
