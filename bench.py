@@ -388,7 +388,7 @@ def main():
     # step_ms list below): in three of five first runs on a fresh box two steps about one second into the back-to-back load
     # took 325 ms instead of 106 (a one-off stall of ~440 ms, the same kernels, gone in the next process on that box) while
     # single steps bracketed by synchronisations had already settled at 106 ms -- so the settling is judged on BLOCKS of 5
-    # back-to-back steps, the way the timed region runs: at least 3 blocks, until two consecutive blocks agree within 1.5 %,
+    # back-to-back steps, the way the timed region runs: at least 4 blocks, until two consecutive blocks agree within 1.5 %,
     # at most 8 (40 untimed steps, ~4 s).  With several ranks the count is FIXED (4 blocks): a data-dependent exit would let
     # ranks enter the timed region after different numbers of steps.  Blocks taken and their per-step times go into the JSON
     # line (settle_steps / settle_ms); no collective inside.
@@ -410,7 +410,7 @@ def main():
         torch.cuda.synchronize(device)
         dt = (time.perf_counter() - t_s) / SETTLE_BLOCK
         settle_ms.append(1e3 * dt)
-        if world == 1 and i_blk >= 2 and prev is not None and abs(dt - prev) <= 0.015 * prev:
+        if world == 1 and i_blk >= 3 and prev is not None and abs(dt - prev) <= 0.015 * prev:
             break
         prev = dt
     for _ in range(args.warmup):
@@ -422,19 +422,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    MSDA.kernel_timing(True)           # HIP events around every MSDeformAttn launch, on the launch stream
+    # Every event the timed region will record is created and recorded once BEFORE it (pctrans_amd/_timing.reserve: the runtime
+    # allocates an event's profiling signal at its first record, in pools that grow in steps): count one warm-up step's
+    # hook-timed launches, then reserve two events per launch for all timed steps.
+    from pctrans_amd import _timing as _kt
+    MSDA.kernel_timing(True)
+    step()
+    per_step = _kt.count()
+    MSDA.kernel_timing(False)
+    _kt.reserve(2 * per_step * (args.steps + 1) + 16, device)
+    step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    for e in step_marks:
+        e.record()
+    MSDA.kernel_timing(True)           # HIP events around every hook-timed launch, on the launch stream
     fence()
     t0 = time.perf_counter()
-    step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     step_marks[0].record()
+    rec_marks = [_kt.count()]
     for i_step in range(args.steps):
         pred = step()
         step_marks[i_step + 1].record()       # one event per step: a straggler step shows in the JSON (step_ms)
+        rec_marks.append(_kt.count())         # ... and which of the hook-timed launches belong to it
     fence()
     elapsed = time.perf_counter() - t0
     gc.enable()
     step_ms = [step_marks[i].elapsed_time(step_marks[i + 1]) for i in range(args.steps)]
     launches = MSDA.kernel_timing(False)
+    # per step: the sum of the hook-timed launches (MSDeformAttn, fused FFN, mask head, attention: ~70 % of a step) and the longest
+    # one -- a straggler step whose timed kernels took their usual time stalled BETWEEN kernels (host, runtime, an untimed kernel)
+    step_timed = [round(sum(r[1] for r in launches[rec_marks[i]:rec_marks[i + 1]]), 2) for i in range(args.steps)]
+    step_longest = [max(((r[1], r[0]) for r in launches[rec_marks[i]:rec_marks[i + 1]]), default=(0.0, ""))
+                    for i in range(args.steps)]
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else device)
     per_rank = [elapsed]
@@ -478,6 +496,8 @@ def main():
             "warmup": args.warmup,
             "settle_steps": SETTLE_BLOCK * len(settle_ms), "settle_ms": [round(x, 2) for x in settle_ms],
             "step_ms": [round(x, 2) for x in step_ms],
+            "step_timed_kernels_ms": step_timed,
+            "step_longest_timed_kernel": ["%.2f %s" % sl for sl in step_longest],
             "ms_per_step": 1e3 * elapsed / args.steps,
             "miopen_dirs_rank0": MIOPEN_DIRS or None,
             "ms_per_step_per_rank": {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps,

@@ -3,6 +3,7 @@ launch stream right before and after a kernel is enqueued.  Off by default; neve
 import torch
 
 _TIMING = None
+_POOL = []            # events created AND recorded once before a timed region (reserve): taken before new ones are made
 
 
 def kernel_timing(enable):
@@ -20,6 +21,28 @@ def kernel_timing(enable):
     return out
 
 
+def reserve(n, device=None):
+    """Create n timing events and record each once now.  The runtime allocates an event's profiling signal at its first record,
+    in pools that grow in steps; a timed region that records hundreds of fresh events can hit such a growth (bench.py, round 4:
+    one step of 446 ms among steps of 91.7, two steps into the region that starts recording ~80 events per step).  Events
+    reserved here are handed out by `timed` before any new one is created."""
+    stream = torch.cuda.current_stream(device)
+    fresh = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+    for e in fresh:
+        e.record(stream)
+    stream.synchronize()
+    _POOL.extend(fresh)
+
+
+def _event():
+    return _POOL.pop() if _POOL else torch.cuda.Event(enable_timing=True)
+
+
+def count():
+    """Launches recorded so far (0 when timing is off): lets a caller attribute the records to its own phases."""
+    return len(_TIMING) if _TIMING is not None else 0
+
+
 class timed:
     """Context manager around one launch; `t` is any tensor on the launch device."""
 
@@ -29,8 +52,8 @@ class timed:
 
     def __enter__(self):
         if _TIMING is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0 = _event()
+            self.e1 = _event()
             self.e0.record(torch.cuda.current_stream(self.t.device))
 
     def __exit__(self, *exc):

@@ -5,6 +5,10 @@
 #pragma once
 #include "msda_common.hpp"
 
+#ifndef PCT_DMH_L2_MFMA
+#define PCT_DMH_L2_MFMA 1
+#endif
+
 namespace pct {
 
 typedef __bf16 dm_bf16x4 __attribute__((ext_vector_type(4)));
@@ -121,8 +125,15 @@ struct DmhPair {
   static constexpr int OFF_B1 = OFF_B0 + HID, OFF_B2 = OFF_B1 + HID;
   static constexpr int PREP_DWORDS = 20;                          // prepared form: a0 (4), a1 (2), b0 (4), b1 (4), w2 (4), b2, pad
   dm_u32x4 a0;
-  dm_s16x4 a1;
+  dm_s16x4 a1, a2;
   float b0v[4], b1v[4], w2v[4], b2;
+  // layer 2 (8 -> 1 per query) as a third MFMA: A rows 0 and 4 carry the first query's weights, rows 8 and 12 the second's, the
+  // other rows are zero -- the accumulator register 0 of lane (pixel, g) is then row 4 g = its own query's logit.  This lane's A
+  // slots k = 4g .. 4g+3 are the hidden units its w2v[] belong to.
+  __device__ __forceinline__ void make_a2(const int col, const int g)
+  {
+    a2 = ((col & 3) == 0 && (col >> 3) == (g >> 1)) ? pack_bf16x4(w2v[0], w2v[1], w2v[2], w2v[3]) : dm_s16x4{0, 0, 0, 0};
+  }
 
   // the pair's parameters as loaded (fetch) and as the MFMAs take them (prepare)
   struct Raw {
@@ -176,6 +187,7 @@ struct DmhPair {
       w2v[r] = w.w2[r];
     }
     b2 = w.b2;
+    make_a2(col, g);
     if (g >= 2) a0 = dm_u32x4{0u, 0u, 0u, 0u};
     if constexpr (REL) {
       const float rx = w.rx * (float)(W * stride), ry = w.ry * (float)(H * stride);
@@ -235,6 +247,8 @@ struct DmhPair {
       b1v[r] = f1[r];
       w2v[r] = f2[r];
     }
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    make_a2(lane & 15, lane >> 4);
   }
 
   // fp32 logits of query (g >> 1) at the lane's pixel column of NT tiles: the same value in both groups of a query.
@@ -255,6 +269,17 @@ struct DmhPair {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       c1[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, xb[t], dm_f32x4{b1v[0], b1v[1], b1v[2], b1v[3]}, 0, 0, 0);
+#if PCT_DMH_L2_MFMA
+    // layer 2 on the matrix cores too (per tile: 2 conversions + 2 packed maxima + 1 MFMA instead of 4 maxima, 4 FMAs, a lane
+    // swap and 2 additions -- the kernel is bound by vector issue, its matrix pipe 18 % busy); its input is rounded to bf16 as
+    // the reference's autocast convolution rounds it
+    dm_s16x4 xc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xc[t] = dm_relu_packed(pack_bf16x4(c1[t][0], c1[t][1], c1[t][2], c1[t][3]));
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      out[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2, xc[t], dm_f32x4{b2, b2, b2, b2}, 0, 0, 0)[0];
+#else
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       float part = 0.f;
@@ -270,6 +295,7 @@ struct DmhPair {
       asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(pa), "+v"(pb));
       out[t] = (pa + pb) + b2;
     }
+#endif
   }
 };
 
