@@ -58,7 +58,8 @@ PCT_API const char *pct_error_string(int code);
  * asserts experiment=0 and all knock-outs off for the library the tests run on). */
 PCT_API const char *pct_build_info(void);
 /* Allocates, for the CURRENT device, the small device-side pools some kernels keep for the life of the process (work-queue
- * counters of the persistent MSDeformAttn kernels: 136 KB; per-item flag buffers of the pyramid-column backward: 64 MB).
+ * counters of the persistent MSDeformAttn kernels: 136 KB; per-item flag buffers of the pyramid-column backward: 64 MB) and sets
+ * the fused FFN kernel's dynamic-LDS attribute.
  * Optional -- the first launch that needs a pool allocates it lazily -- but that lazy path allocates and synchronises the
  * device, which must not happen while ANY stream of the process is being captured into a HIP graph (a launch that finds its
  * pool missing under capture runs on another kernel instead: pct_msda_last_kernel / pct_msda_last_bwd_kernel tell).  Call it

@@ -43,6 +43,7 @@ int prepare_msda_backward_col_device();
 const char *msda_forward_col_build_flags();
 const char *msda_backward_col_build_flags();
 const char *ffn_fused_build_flags();
+int prepare_ffn_device();
 int launch_msda_forward_planes(const void *, const int64_t *, const int64_t *, const void *, const void *, int, int, int, int,
                                int, int, int, void *, hipStream_t, const float *, long long);
 int launch_ffn_fused_split(const float *, long long, const float *, const float *, const float *, const float *, const float *,
@@ -498,7 +499,8 @@ int pct_prepare_device(void)
   (void)cap;
   const int a = pct::prepare_win_queue_device();
   const int b = pct::prepare_msda_backward_col_device();
-  return a ? a : b;
+  const int c = pct::prepare_ffn_device();
+  return a ? a : (b ? b : c);
 }
 
 const char *pct_build_info(void)

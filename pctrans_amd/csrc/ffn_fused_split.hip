@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <type_traits>
+#include "msda_win_common.hpp"    // func_attr_per_device
 
 // knock-outs (WRONG RESULTS, timing only): 1 = no image transport inside the chunk loop, 2 = no bias / ReLU / split arithmetic,
 // 4 = no barrier per chunk, 16 / 32 = of the transport only the LDS stores / only the loads, 8 = no residual loads, 64 = no y stores
@@ -483,6 +484,9 @@ __global__ __launch_bounds__(FF_BLOCK, 1) void ffn_fused_split_kernel(
 #define PCT_FF_STR(x) PCT_FF_STR2(x)
 const char *ffn_fused_build_flags() { return "ffn: KO=" PCT_FF_STR(PCT_FFN_KO) " STAMPS=" PCT_FF_STR(PCT_FFN_STAMPS) " SPREAD=" PCT_FF_STR(PCT_FFN_SPREAD); }
 
+// the kernel's LDS attribute for the current device, outside any stream capture (pct_prepare_device)
+int prepare_ffn_device() { return func_attr_per_device(reinterpret_cast<const void *>(&ffn_fused_split_kernel), FF_LDS) == hipSuccess ? 0 : -4; }
+
 // img_ws: (F / 32) * 57 344 bytes, 16-byte aligned, refilled on every call.  -4: geometry not covered.
 int launch_ffn_fused_split(const float *x, long long ldx, const float *w1, const float *b1, const float *w2, const float *b2,
                            const float *gamma, const float *beta, float eps, int F, long long rows, void *img_ws, float *out,
@@ -492,15 +496,7 @@ int launch_ffn_fused_split(const float *x, long long ldx, const float *w1, const
   if (F <= 0 || F % FF_CH) return -4;
   if ((long long)(F / FF_CH) * FF_STAGE > 0x7fffffffLL) return -4;
   if (32LL * (ldx > ldo ? ldx : ldo) * 4 > 0x7fffffffLL) return -4;
-  static thread_local int attr_dev = -1;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return -4;
-  if (attr_dev != dev) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ffn_fused_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            FF_LDS) != hipSuccess)
-      return -4;
-    attr_dev = dev;
-  }
+  if (func_attr_per_device(reinterpret_cast<const void *>(&ffn_fused_split_kernel), FF_LDS) != hipSuccess) return -4;
   const long long pairs = (long long)F * FF_D + F / 2;            // element pairs of both matrices and the bias
   hipLaunchKernelGGL(ffn_split_weights_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, stream, w1, w2, b1, F,
                      static_cast<unsigned short *>(img_ws));

@@ -271,6 +271,7 @@ def ffn_layer_norm(x, linear1, linear2, norm):
     ptrs = [x2, linear1.weight, linear1.bias, linear2.weight, norm.weight, norm.bias] + ([linear2.bias] if linear2.bias is not None else [])
     if not (all(t.data_ptr() % 16 == 0 for t in ptrs) and x2.stride(0) % 4 == 0):
         return linear_layer_norm(linear(x, linear1, relu=True), linear2, x, norm)
+    _lib.prepare_device(x.device)
     stream = torch.cuda.current_stream(x.device).cuda_stream
     key = (x.device, stream, f)
     ws = _FFN_WS.get(key)
