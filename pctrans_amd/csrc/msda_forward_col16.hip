@@ -526,26 +526,35 @@ __global__ __launch_bounds__(BLOCK, 3) void msda_forward_col16_kernel(
       __builtin_amdgcn_sched_barrier(0);
     };
 
+    // stage the windows of one phase by LDS-DMA, ROW-WISE as msda_forward_col.hip does: one wave instruction copies 64
+    // consecutive 16-byte pieces = 32 pixels of ONE window row, the waves take the rows in turn; a lane's source offset is
+    // a per-lane part that depends on its column only (once per level and 32-pixel column block) plus a uniform per-row
+    // part in the instruction's scalar offset -- no vector arithmetic per copy (the piece-linear indexing this replaces
+    // divided by the window width for every piece).  Columns / rows outside the map use an out-of-range offset: zeros.
     auto stage_phase = [&](const int phx) {
+      constexpr int PPX = PXB / 16, CPX = 64 / PPX;
+      constexpr unsigned OOB = 0x80000000u;
+      const int ln = tid & 63;
+      const int dx = ln / PPX, cc = ln & (PPX - 1);
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const unsigned MDb = (unsigned)MD * 2u;                                 // bytes per pixel, all heads
 #pragma unroll
       for (int l = 0; l < L; ++l) {
         if (phase_of[l] == phx && wsize[l] > 0) {
-          const float inv_w = uni(1.0f / (float)wwid[l]);
-          const int n16 = wsize[l] * 2;
-          const unsigned lvl_off = (unsigned)St[l] * (unsigned)MD * 2u + (unsigned)(m * D) * 2u;
+          const unsigned lvl_off = (unsigned)St[l] * MDb + (unsigned)(m * D) * 2u;
+          const unsigned row_bytes = (unsigned)Ws[l] * MDb;
           unsigned char *dst = pool + (size_t)wbase[l] * PXB;
-          for (int it = 0; it * BLOCK < n16; ++it) {
-            const int i = it * BLOCK + tid;
-            if (i < n16) {
-              const int px = i >> 1, cc = i & 1;
-              const int r = (int)(((float)px + 0.5f) * inv_w);
-              const int y = wy0[l] + r, x = wx0[l] + px - r * wwid[l];
-              const bool inside = (unsigned)y < (unsigned)Hs[l] && (unsigned)x < (unsigned)Ws[l];
-              const unsigned off = inside ? lvl_off + (unsigned)(y * Ws[l] + x) * ((unsigned)MD * 2u) + (unsigned)(cc * 16)
-                                          : 0x80000000u;
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                  rsrc, (__attribute__((address_space(3))) void *)(dst + (size_t)(it * BLOCK + (tid & ~63)) * 16), 16,
-                  (int)off, 0, 0, 0);
+          for (int c0 = 0; c0 < wwid[l]; c0 += CPX) {
+            const int xw = c0 + dx, x = wx0[l] + xw;
+            const unsigned voff = (unsigned)x < (unsigned)Ws[l] ? (unsigned)x * MDb + (unsigned)(cc * 16) : OOB;
+            if (xw < wwid[l]) {
+              for (int r = wv; r < whgt[l]; r += NW) {
+                const int y = wy0[l] + r;
+                const bool in_y = (unsigned)y < (unsigned)Hs[l];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rsrc, (__attribute__((address_space(3))) void *)(dst + (size_t)(r * wwid[l] + c0) * PXB), 16,
+                    (int)(in_y ? voff : OOB), (int)(in_y ? lvl_off + (unsigned)y * row_bytes : 0u), 0, 0);
+              }
             }
           }
         }

@@ -161,3 +161,113 @@ def graph_training_front(model, example_volume, warmup=3):
         m.__dict__["__reduce_ex__"] = _no_copy            # pickle / torch.save(model) of the whole module
     model.train(was_training)
     return model
+
+
+class _DecoderCore(torch.nn.Module):
+    """The transformer decoder's static-shape tensor flow as a module of its own (tensors in, a flat tuple of tensors out);
+    holds the decoder as a sub-module so that its parameters are part of the captured backward."""
+
+    def __init__(self, decoder):
+        super().__init__()
+        self.decoder = decoder
+
+    def forward(self, mask_features, *multi_scale_features):
+        return self.decoder._forward_core(mask_features, *multi_scale_features)
+
+
+def has_graphed_decoder(model):
+    return "_pct_graphed_core" in model.sem_seg_head.predictor.__dict__
+
+
+def graph_training_decoder(model, example_volume, warmup=3):
+    """Capture the transformer decoder's STATIC-SHAPE core -- input projections, the nine cross-attention / self-attention /
+    FFN layers, reference-point updates, the ten dynamic mask heads and the semantic head, forward AND backward -- as HIP
+    graphs (torch.cuda.make_graphed_callables), in place.  This is the host-bound part of a training step at the
+    reference's per-GPU batch of two crops (thousands of launches on [Q, N, C]-sized tensors); what follows the matching --
+    the ten Hungarian assignments, the query-contrast items and the criterion -- stays eager (its shapes follow the
+    targets).  `MultiScaleMaskedTransformerDecoder.forward` evaluates the core first and the matching afterwards in the
+    eager path too, so eager and replayed steps run the same operations in the same order.
+
+    Same restrictions as graph_training_front (single-rank or frozen-norm: the semantic head's BatchNorm is inside the
+    core; outside torch.autocast; fixed crop size and batch; no deep copy / pickle of the captured model), decoder dropout
+    must be 0 (the shipped configurations: a captured dropout mask would repeat).  May be combined with
+    graph_training_front in either order.  Returns the model."""
+    head = model.sem_seg_head
+    decoder = head.predictor
+    if "_pct_graphed_core" in decoder.__dict__:
+        raise RuntimeError("graph_training_decoder: this model's decoder is already captured")
+    import torch.distributed as dist
+    multi_rank = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    for name, m in decoder.named_modules():
+        if isinstance(m, torch.nn.SyncBatchNorm):
+            raise RuntimeError("graph_training_decoder: predictor.%s is a SyncBatchNorm -- its cross-rank all_gather cannot be "
+                               "captured into a HIP graph; capture on a single-rank / frozen-norm model only" % name)
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and multi_rank:
+            raise RuntimeError("graph_training_decoder: predictor.%s is a BatchNorm and %d ranks are running -- the captured "
+                               "graphs would keep per-rank statistics where the reference synchronises them (build.py:80-81)"
+                               % (name, dist.get_world_size()))
+        if isinstance(m, torch.nn.Dropout) and m.p > 0:
+            raise RuntimeError("graph_training_decoder: predictor.%s has dropout %g -- a captured mask would repeat" % (name, m.p))
+        if isinstance(getattr(m, "dropout", None), float) and m.dropout > 0:
+            raise RuntimeError("graph_training_decoder: predictor.%s has attention dropout %g" % (name, m.dropout))
+    if torch.is_autocast_enabled():
+        raise RuntimeError("graph_training_decoder: call outside torch.autocast (see graph_training_front)")
+    was_training = model.training
+    model.train()
+    owned = list(model.named_buffers())                   # (the example pass below runs backbone + pixel decoder in training mode too)
+    buffers = {n: b.detach().clone() for n, b in owned}
+    # example inputs of the core: one eager pass through backbone + pixel decoder (graphed or not: only shapes are used)
+    with torch.no_grad():
+        feats = model.backbone(example_volume)
+        mask_features, _enc, multi = head.pixel_decoder.forward_features(feats)
+    sample = tuple(t.detach().clone().requires_grad_(True) for t in (mask_features,) + tuple(multi))
+    shapes = tuple((tuple(t.shape), t.dtype) for t in sample)
+    g_core = torch.cuda.make_graphed_callables(_DecoderCore(decoder), sample, num_warmup_iters=warmup,
+                                               allow_unused_input=True)
+    with torch.no_grad():                                 # the example / warm-up / capture passes ran BatchNorms in training mode
+        for n, b in owned:
+            b.copy_(buffers[n])
+
+    def core(mask_features, *multi_scale_features):
+        if torch.is_autocast_enabled():
+            raise RuntimeError("the graphed decoder core was captured outside autocast and replays as captured: run it "
+                               "outside torch.autocast")
+        got = tuple((tuple(t.shape), t.dtype) for t in (mask_features,) + tuple(multi_scale_features))
+        if got != shapes:
+            raise ValueError("graph_training_decoder was captured for %s, got %s" % (shapes, got))
+        return g_core(mask_features, *multi_scale_features)
+
+    def _no_copy(*_a, **_k):
+        raise RuntimeError("a model whose decoder is captured (graph_training_decoder) cannot be deep-copied or pickled: "
+                           "its forward drives the original model's HIP graphs -- copy the state dict instead")
+
+    decoder.__dict__["_pct_graphed_core"] = core
+    decoder.__dict__["__deepcopy__"] = _no_copy
+    decoder.__dict__["__reduce_ex__"] = _no_copy
+    model.train(was_training)
+    return model
+
+
+def release_training_graphs(model):
+    """Undo graph_training_front / graph_training_decoder: the modules run eagerly again and the captured HIP graphs (with their
+    private memory pools) are destroyed HERE, on the calling thread, after the device has drained -- not whenever Python's
+    cyclic collector finds the closures (which may be inside another model's replay, on autograd's worker thread: destroying a
+    graph while one is being launched crashed the HIP runtime in tools/record_train_configs.py, which builds several captured
+    models in one process).  Call it before dropping a captured model in a process that goes on using the device."""
+    import gc
+    head = model.sem_seg_head
+    torch.cuda.synchronize()
+    for mod, attr in ((model.backbone, "forward"), (head.pixel_decoder, "forward_features")):
+        if "_pct_graphed" in mod.__dict__:
+            del mod.__dict__["_pct_graphed"]
+            mod.__dict__.pop(attr, None)                  # the instance attribute shadowing the class's eager method
+            mod.__dict__.pop("__deepcopy__", None)
+            mod.__dict__.pop("__reduce_ex__", None)
+    dec = head.predictor
+    if "_pct_graphed_core" in dec.__dict__:
+        del dec.__dict__["_pct_graphed_core"]
+        dec.__dict__.pop("__deepcopy__", None)
+        dec.__dict__.pop("__reduce_ex__", None)
+    gc.collect()
+    torch.cuda.synchronize()
+    return model

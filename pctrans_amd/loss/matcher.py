@@ -129,11 +129,32 @@ class Point_HungarianMatcher(nn.Module):
         self.pending_status.append(status)
         if len(self.pending_status) > 256:             # nobody called check(): fold the backlog into one flag tensor
             self.pending_status = [torch.cat(self.pending_status).max().reshape(1)]
-        out = []
-        for b, g in enumerate(counts):
-            i, order = torch.sort(rows[b, :g].long())          # scipy lists the pairs by ascending prediction index
-            out.append((i, order))
-        return out
+        # scipy lists the pairs by ascending prediction index: one sort for all problems (unmatched columns hold -1 and are
+        # moved behind every query index first; a problem's matched queries are distinct, so its first g entries are the
+        # per-problem sort)
+        vals, order = torch.sort(torch.where(rows < 0, padded.shape[1], rows).long(), dim=1)
+        return [(vals[b, :g], order[b, :g]) for b, g in enumerate(counts)]
+
+    @torch.no_grad()
+    def forward_many(self, outputs_list, targets):
+        """The matchings of several predictions against the same targets -- the decoder's ten prediction heads -- as one
+        call: the cost matrices are formed prediction by prediction exactly as `forward` forms them (same random points
+        in the same order), all assignment problems then go to the device in ONE launch (a 300 x 60 problem keeps one
+        workgroup busy for about a millisecond: ten launches of two problems each left the other 254 compute units idle
+        for 10 ms of every BASELINE configs[3] training step).  -> [forward(o, targets) for o in outputs_list]."""
+        if not outputs_list:
+            return []
+        pred = outputs_list[0]["pred_masks"]
+        bs, num_queries = pred.shape[:2]
+        counts = [int(t["masks"].shape[0]) for t in targets]
+        sizes = {tuple(t["masks"].shape[-2:]) for t in targets}
+        same = all(o["pred_masks"].shape[:2] == pred.shape[:2] and o["pred_masks"].is_cuda for o in outputs_list)
+        if not (self.batch_images and self.device_lsap and same and bs > 0 and len(sizes) == 1 and 0 < max(counts) <= min(num_queries, 512)
+                and num_queries <= 1024):
+            return [self.memory_efficient_forward(o, targets) for o in outputs_list]
+        costs = [self._batched_costs(o, targets)[0] for o in outputs_list]
+        flat = self._assign_padded(torch.cat(costs), counts * len(outputs_list))
+        return [flat[k * bs:(k + 1) * bs] for k in range(len(outputs_list))]
 
     def check(self):
         """Raise if any assignment since the last call was infeasible (one host synchronisation)."""

@@ -78,8 +78,8 @@ def init_devices(distributed=None, backend="nccl", manual_seed=None, share_gpu=F
 
 
 def has_graphed_front(model):
-    """True when pctrans_amd.graph.graph_training_front captured part of this model into HIP graphs."""
-    return any("_pct_graphed" in m.__dict__ for m in model.modules())
+    """True when pctrans_amd.graph.graph_training_front / graph_training_decoder captured part of this model into HIP graphs."""
+    return any("_pct_graphed" in m.__dict__ or "_pct_graphed_core" in m.__dict__ for m in model.modules())
 
 
 def convert_norms(model):

@@ -41,6 +41,9 @@ from .position_encoding import PositionEmbeddingSine
 _SINE_TABLES = {}
 
 
+_HEAD_TABLES = {}
+
+
 def gen_sineembed_for_position(pos_tensor, temperature=20):
     """[Q, N, 2k] normalised (x, y) points -> [Q, N, 256k] sine embedding, (y, x) order per point.
 
@@ -394,8 +397,52 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
 
     # ------------------------------------------------------------------------------------------------------
     def forward(self, x, targets, mask_features, mask=None, attn_mask_threshold=0.5, criterion=None):
+        """dec.py:502-645.  The tensor flow of the decoder (`_forward_core`: every shape follows (Q, N, feature sizes) only)
+        is evaluated first, then the Hungarian matching of its ten mask predictions and the query-contrast items, whose
+        shapes follow the targets.  The reference calls the matcher between the layers (:569, :627); its result is not read
+        before the last layer's contrast items (:631-640) and the criterion, and the matcher is the only consumer of random
+        numbers here (dropout 0), so the values and the random stream are those of the interleaved order.  The split is what
+        lets graph.graph_training_decoder replay the core (forward and backward) from HIP graphs."""
         assert len(x) == self.num_feature_levels
         del mask          # padding masks are not applied on this path (:509-510)
+        graphed = self.__dict__.get("_pct_graphed_core")
+        if graphed is not None and self.training and torch.is_grad_enabled():
+            flat = graphed(mask_features, *x)
+        else:
+            flat = self._forward_core(mask_features, *x)
+        n_pred = self.num_layers + 1
+        output, outputs_coords = flat[0], flat[1]
+        predictions_mask = list(flat[2:2 + n_pred])
+        sem_logits_pred = flat[2 + n_pred] if self.sem_loss_on else None
+
+        indices_list = []
+        if targets is not None:
+            many = getattr(criterion.matcher, "forward_many", None)
+            if many is not None:                    # all heads' assignment problems in one device launch
+                indices_list = many([{"pred_masks": pm} for pm in predictions_mask], targets)
+            else:
+                indices_list = [criterion.matcher({"pred_masks": pm}, targets) for pm in predictions_mask]
+            from .query_contrast import query_contrast_items
+            contrast_items_query, contrast_items_mask = query_contrast_items(output, predictions_mask[-1], indices_list[-1])
+
+        out = {
+            "pred_masks": predictions_mask[-1],
+            "aux_outputs": self._set_aux_loss(predictions_mask),
+            "reference_points": outputs_coords[-1],
+            "aux_reference_points": self._set_refpoints_aux_loss(outputs_coords),
+            "indices_list": indices_list,
+        }
+        if targets is not None:
+            out["pred_qd_query"] = contrast_items_query
+            out["pred_qd_mask"] = contrast_items_mask
+        if self.sem_loss_on:
+            out["sem_mask"] = sem_logits_pred
+        return out
+
+    def _forward_core(self, mask_features, *x):
+        """Everything of `forward` whose shapes do not depend on the targets.  Tensors in, a flat tuple of tensors out (what
+        torch.cuda.make_graphed_callables captures): (query features [Q, N, C], stacked reference points [layers, N, Q, 2],
+        the num_layers + 1 mask predictions, [semantic logits])."""
         src, pos, size_list = [], [], []
         for i in range(self.num_feature_levels):
             size_list.append(x[i].shape[-2:])
@@ -408,7 +455,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         query_embed = _lp(self.query_embed.weight.unsqueeze(1).repeat(1, bs, 1))  # Q x N x C
         output = self.query_feat.weight.unsqueeze(1).repeat(1, bs, 1)
 
-        predictions_mask, outputs_coords, indices_list = [], [], []
+        predictions_mask, outputs_coords = [], []
         out_lp = None
         reference_points = self.ref_point_head(query_embed).sigmoid()
         ref_points = [reference_points]
@@ -432,10 +479,6 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             mask_feat, reference_points, self.controller(output), mask_feat_stride=4, rel_coord=self.rel_coord,
             attn_mask_target_size=size_list[0], _feats_f32=feats_f32)
         predictions_mask.append(outputs_mask)
-        indices = None
-        if targets is not None:
-            indices = criterion.matcher({"pred_masks": outputs_mask}, targets)
-            indices_list.append(indices)
 
         for i in range(self.num_layers):
             query_sine_embed = gen_sineembed_for_position(reference_points)
@@ -464,9 +507,6 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
                 mask_feat, new_reference_points, self.controller(out_lp), mask_feat_stride=4,
                 rel_coord=self.rel_coord, attn_mask_target_size=size_list[(i + 1) % self.num_feature_levels],
                 _feats_f32=feats_f32)
-            if targets is not None:
-                indices = criterion.matcher({"pred_masks": outputs_mask}, targets)
-                indices_list.append(indices)
 
             decoder_output = self.decoder_norm(output).transpose(0, 1)
             outputs_coord = (self.point_embed(decoder_output).float()
@@ -474,24 +514,10 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             predictions_mask.append(outputs_mask)
             outputs_coords.append(outputs_coord)
 
-            if i == self.num_layers - 1 and targets is not None:
-                from .query_contrast import query_contrast_items
-                contrast_items_query, contrast_items_mask = query_contrast_items(output, outputs_mask, indices)
-
-        outputs_coords = torch.stack(outputs_coords)
-        out = {
-            "pred_masks": predictions_mask[-1],
-            "aux_outputs": self._set_aux_loss(predictions_mask),
-            "reference_points": outputs_coords[-1],
-            "aux_reference_points": self._set_refpoints_aux_loss(outputs_coords),
-            "indices_list": indices_list,
-        }
-        if targets is not None:
-            out["pred_qd_query"] = contrast_items_query
-            out["pred_qd_mask"] = contrast_items_mask
+        flat = (output, torch.stack(outputs_coords)) + tuple(predictions_mask)
         if self.sem_loss_on:
-            out["sem_mask"] = sem_logits_pred
-        return out
+            flat = flat + (sem_logits_pred,)
+        return flat
 
     # ------------------------------------------------------------------------------------------------------
     def dynamic_mask_with_coords(self, mask_feats, reference_points, mask_head_params, mask_feat_stride, rel_coord,
@@ -536,9 +562,18 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
 
         if rel_coord:
             # x0[q,k,p] = sum_c w0[q,k,2+c] F[c,p] + w0[q,k,0] * (rx_q - lx_p) + w0[q,k,1] * (ry_q - ly_p) + b0[q,k]
-            scale = ref_xy.new_tensor([W * mask_feat_stride, H * mask_feat_stride])
+            # (both depend on the map's shape only: built once per shape and device -- ten heads per forward would otherwise
+            # rebuild them with a dozen small kernels and one pageable host->device copy each, which also cannot be
+            # captured into a HIP graph)
+            key = (H, W, mask_feat_stride, mask_feats.device, ref_xy.dtype)
+            tab = _HEAD_TABLES.get(key)
+            if tab is None:
+                if len(_HEAD_TABLES) > 16:
+                    _HEAD_TABLES.clear()
+                tab = _HEAD_TABLES[key] = (ref_xy.new_tensor([W * mask_feat_stride, H * mask_feat_stride]),
+                                           compute_locations(H, W, stride=mask_feat_stride, device=mask_feats.device))
+            scale, loc = tab                                                         # [2], [HW, 2]
             inst = ref_xy * scale                                                    # [N, Q, 2]
-            loc = compute_locations(H, W, stride=mask_feat_stride, device=mask_feats.device)   # [HW, 2]
             rel = (inst[:, :, None, :] - loc[None, None, :, :]).float()              # [N, Q, HW, 2]
             x = torch.bmm(w0[..., 2:].reshape(N, Q * ch, C), feats).view(N, Q, ch, H * W)
             x = torch.addcmul(x, w0[..., 0:1], rel[:, :, None, :, 0])

@@ -287,6 +287,25 @@ def test_matcher_batched_costs_equal_the_per_image_loop():
     assert len(m({"pred_masks": pred}, targets)) == 3
 
 
+def test_matcher_forward_many_equals_one_call_per_prediction():
+    """forward_many (the decoder's ten heads in one call) = forward per prediction with the same random stream; on CPU tensors
+    it takes the per-call path."""
+    torch.manual_seed(6)
+    preds = [torch.randn(2, 9, 12, 12) * 3 for _ in range(4)]
+    targets = [{"masks": (torch.rand(g, 24, 24) < 0.3).float()} for g in (3, 5)]
+    m = Point_HungarianMatcher(cost_mask=5.0, cost_dice=2.0, num_points=64)
+    torch.manual_seed(2)
+    one_by_one = [m({"pred_masks": p}, targets) for p in preds]
+    torch.manual_seed(2)
+    many = m.forward_many([{"pred_masks": p} for p in preds], targets)
+    assert len(many) == len(preds)
+    for a, b in zip(many, one_by_one):
+        assert len(a) == len(b) == 2
+        for (i, j), (k, l) in zip(a, b):
+            assert i.tolist() == k.tolist() and j.tolist() == l.tolist()
+    assert m.forward_many([], targets) == []
+
+
 # ---- instance_inference end to end (arch/maskformer.py:267-346 of the reference) ----------------------------------------
 def _instance_inference_literal(mask_pred, dataset):
     """The reference's instance_inference restated line by line for both dataset branches (its CVPPP branch cannot run as

@@ -460,6 +460,39 @@ def test_matcher_on_device_equals_the_scipy_path():
         assert torch.equal(i.cpu(), ih) and torch.equal(j.cpu(), jh)
 
 
+def test_matcher_forward_many_is_one_launch_with_the_per_call_results():
+    """Point_HungarianMatcher.forward_many: ten predictions' assignment problems in ONE device launch = ten calls of forward
+    with the same random stream (ragged target counts, an image without targets), and the host path when the device solver
+    is switched off."""
+    from pctrans_amd import fused_ops
+    from pctrans_amd.loss.matcher import Point_HungarianMatcher
+    torch.manual_seed(0)
+    preds = [torch.randn(3, 50, 32, 32, device="cuda") * 2 for _ in range(10)]
+    targets = [{"masks": (torch.rand(g, 64, 64, device="cuda") > 0.5).float()} for g in (7, 0, 20)]
+    m = Point_HungarianMatcher(cost_mask=5.0, cost_dice=5.0, num_points=256)
+    torch.manual_seed(1)
+    ref = [m({"pred_masks": p}, targets) for p in preds]
+    calls = []
+    real = fused_ops.lsap
+    fused_ops.lsap = lambda c, n: (calls.append(tuple(c.shape)), real(c, n))[1]
+    try:
+        torch.manual_seed(1)
+        many = m.forward_many([{"pred_masks": p} for p in preds], targets)
+    finally:
+        fused_ops.lsap = real
+    m.check()
+    assert calls == [(30, 50, 20)]
+    for a, b in zip(many, ref):
+        for (i, j), (k, l) in zip(a, b):
+            assert i.is_cuda and i.dtype == torch.int64 and torch.equal(i, k) and torch.equal(j, l)
+    m.device_lsap = False
+    torch.manual_seed(1)
+    host = m.forward_many([{"pred_masks": p} for p in preds], targets)
+    for a, b in zip(host, ref):
+        for (i, j), (k, l) in zip(a, b):
+            assert torch.equal(i, k.cpu()) and torch.equal(j, l.cpu())
+
+
 def test_device_lsap_flags_what_scipy_rejects():
     """scipy.optimize.linear_sum_assignment raises on a NaN or -inf entry anywhere in the matrix and on more columns than
     rows in the transposed call the reference makes (matcher.py:154-165); the device solver reports those problems

@@ -354,6 +354,91 @@ def test_graphed_training_front_gives_the_eager_step(tmp_path):
     with pytest.raises(ValueError):
         graphed.train()
         graphed(vol[:, :, :96], targets, True)
+    # back to eager, graphs destroyed now (not by a collector pass during a later test's replay); same step as before
+    graph.release_training_graphs(graphed)
+    from pctrans_amd import parallel
+    assert not parallel.has_graphed_front(graphed)
+    lr, _ = step(graphed)
+    assert abs(le - lr) <= 2e-4 * max(1.0, abs(le))
+
+
+def test_graphed_training_decoder_gives_the_eager_step():
+    """graph.graph_training_decoder: the transformer decoder's static-shape core (layers, reference points, ten mask heads,
+    semantic head) forward AND backward replayed from HIP graphs, alone and together with the graphed front; matching,
+    contrast items and the criterion eager.  Same losses and gradients as the eager step on the same inputs over three
+    replays, every parameter that has a gradient in the eager step has one in the replayed step, BatchNorm statistics not
+    moved by the capture, eval path untouched, another crop size refused."""
+    import copy
+    import random
+    from pctrans_amd import graph, parallel
+    from pctrans_amd.arch import maskformer as mfm
+    from pctrans_amd.arch.resnet import ResNet
+    from pctrans_amd.config import get_cfg
+    from test_arch_cpu import _blob
+    torch.manual_seed(0)
+    cfg = get_cfg(num_queries=12, norm="BN", sem_norm="BN", enc_layers=2, dec_layers=4, train_num_points=512, dataset="BBBC")
+    eager = mfm.MaskFormer(**mfm.MaskFormer.from_config(cfg, ResNet(18, 3, norm="BN"))).cuda().train()
+    dec_only, both = copy.deepcopy(eager), copy.deepcopy(eager)
+    H = W = 128
+    vol = torch.randn(2, 3, H, W, device="cuda")
+    targets = []
+    for b in range(2):
+        masks = torch.stack([_blob(H, W, 30, 30, 14), _blob(H, W, 90, 80, 20), _blob(H, W, 40, 100 - 9 * b, 10)]).cuda()
+        centers = torch.tensor([[30 / W, 30 / H], [80 / W, 90 / H], [(100 - 9 * b) / W, 40 / H]], device="cuda").view(3, 1, 2)
+        targets.append({"masks": masks, "labels": torch.ones(3, dtype=torch.long, device="cuda"),
+                        "fg_masks": (masks.sum(0) > 0).float(), "center_points": centers})
+    stats = {n: b.clone() for n, b in dec_only.named_buffers()}
+    graph.graph_training_decoder(dec_only, vol)
+    graph.graph_training_decoder(both, vol)
+    graph.graph_training_front(both, vol)
+    assert graph.has_graphed_decoder(dec_only) and parallel.has_graphed_front(dec_only)
+    for model in (dec_only, both):
+        assert sorted(model.state_dict()) == sorted(eager.state_dict())
+        for n, b in model.named_buffers():
+            assert torch.equal(b, stats[n]), n                                    # capture passes did not move the statistics
+
+    def step(model):
+        random.seed(3)
+        torch.manual_seed(3)
+        losses = model(vol, targets, True)
+        total = sum(v for v in losses.values() if torch.is_tensor(v))
+        model.zero_grad(set_to_none=True)
+        total.backward()
+        return ({k: float(v.detach()) for k, v in losses.items() if torch.is_tensor(v)},
+                {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+
+    le, ge = step(eager)
+    for model in (dec_only, both):
+        for _ in range(3):
+            lg, gg = step(model)
+            assert lg.keys() == le.keys()
+            for k in le:
+                assert abs(le[k] - lg[k]) <= 2e-4 * max(1.0, abs(le[k])), (k, le[k], lg[k])
+            assert ge.keys() <= gg.keys()
+            for n in ge:
+                # (key-projection biases have a mathematically zero gradient -- softmax does not see a shift of every key:
+                # what both runs hold there is rounding noise of ~1e-7, compared absolutely)
+                scale = float(ge[n].abs().max())
+                tol = 5e-3 * scale + 1e-6 if scale > 1e-5 else 1e-5
+                assert float((ge[n] - gg[n]).abs().max()) <= tol, n
+            for n in gg.keys() - ge.keys():                                       # (parameters the losses do not reach)
+                assert float(gg[n].abs().max()) == 0.0, n
+    with pytest.raises(RuntimeError, match="already captured"):
+        graph.graph_training_decoder(dec_only, vol)
+    with pytest.raises(RuntimeError, match="cannot be deep-copied"):
+        copy.deepcopy(dec_only)
+    with pytest.raises(ValueError):
+        dec_only(vol[:, :, :96], targets, True)
+    dec_only.eval()
+    eager.eval()
+    with torch.no_grad():
+        a, _ = dec_only(vol)
+        b, _ = eager(vol)
+    assert torch.equal(a, b)                                                      # the eval path is the eager one
+    for model in (dec_only, both):
+        graph.release_training_graphs(model)
+        assert not parallel.has_graphed_front(model) and not graph.has_graphed_decoder(model)
+    copy.deepcopy(dec_only)                                                       # an ordinary module again
 
 
 def test_graphed_training_front_guards():
@@ -387,3 +472,5 @@ def test_graphed_training_front_guards():
     model.eval()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         model.backbone(vol)                                       # the eval path is the eager one and follows autocast
+    graph.release_training_graphs(model)
+    copy.deepcopy(model)                                          # released: an ordinary module again

@@ -53,6 +53,9 @@ def build(c):
         targets.append({"masks": masks, "labels": torch.ones(G, dtype=torch.long, device="cuda"),
                         "fg_masks": (masks.sum(0) > 0).float(), "center_points": centers})
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05)
+    if c.get("graph_decoder"):
+        from pctrans_amd.graph import graph_training_decoder
+        graph_training_decoder(model, vol)
     if c.get("graph_front"):
         from pctrans_amd.graph import graph_training_front
         graph_training_front(model, vol)
@@ -72,6 +75,10 @@ def main():
     configs = dict(CONFIGS)
     if "--graph-front" in sys.argv:
         configs.update({k + " + graphed backbone / pixel decoder": dict(v, graph_front=True) for k, v in CONFIGS.items()})
+    if "--graph-decoder" in sys.argv:
+        configs.update({k + " + graphed decoder core": dict(v, graph_decoder=True) for k, v in CONFIGS.items()})
+        configs.update({k + " + graphed decoder core + backbone / pixel decoder": dict(v, graph_decoder=True, graph_front=True)
+                        for k, v in CONFIGS.items()})
     for name, c in configs.items():
         model, step = build(c)
         for _ in range(3):
@@ -107,7 +114,12 @@ def main():
                    top_device_time_ms={k: round(v / 1e3, 2) for k, v in sorted(top.items(), key=lambda kv: -kv[1])[:12]})
         out["configs"][name] = rec
         print(name, json.dumps(rec), flush=True)
-        del model, step
+        if c.get("graph_front") or c.get("graph_decoder"):
+            from pctrans_amd.graph import release_training_graphs
+            release_training_graphs(model)                # graphs destroyed now, not by a later collector pass inside a replay
+        del model, step, prof
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
     print("JSON " + json.dumps(out))
 
