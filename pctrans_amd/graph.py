@@ -95,6 +95,9 @@ def graph_training_front(model, example_volume, warmup=3):
     backbone, pixel_decoder = model.backbone, head.pixel_decoder
     if "_pct_graphed" in backbone.__dict__:
         raise RuntimeError("graph_training_front: this model's front is already captured")
+    if "_pct_graphed_core" in head.predictor.__dict__:
+        raise RuntimeError("graph_training_front: this model's decoder core is captured (graph_training_decoder) -- use one "
+                           "capture or the other (see graph_training_decoder)")
     import torch.distributed as dist
     multi_rank = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     for owner, mod in (("backbone", backbone), ("pixel_decoder", pixel_decoder)):
@@ -190,12 +193,18 @@ def graph_training_decoder(model, example_volume, warmup=3):
 
     Same restrictions as graph_training_front (single-rank or frozen-norm: the semantic head's BatchNorm is inside the
     core; outside torch.autocast; fixed crop size and batch; no deep copy / pickle of the captured model), decoder dropout
-    must be 0 (the shipped configurations: a captured dropout mask would repeat).  May be combined with
-    graph_training_front in either order.  Returns the model."""
+    must be 0 (the shipped configurations: a captured dropout mask would repeat).  NOT combinable with graph_training_front
+    (either raises when the other is in place): measured, the decoder core alone is the faster capture (configs[2]: 74.9 ms
+    against 80.1 for the front and 77.3 for both), and with both in place a backward graph launch crashed the HIP runtime in
+    two of four processes of tools/record_train_configs.py.  Returns the model."""
     head = model.sem_seg_head
     decoder = head.predictor
     if "_pct_graphed_core" in decoder.__dict__:
         raise RuntimeError("graph_training_decoder: this model's decoder is already captured")
+    if "_pct_graphed" in model.backbone.__dict__ or "_pct_graphed" in head.pixel_decoder.__dict__:
+        raise RuntimeError("graph_training_decoder: this model's front is captured (graph_training_front) -- use one capture or "
+                           "the other: the decoder core alone is the faster of the two, and with both captured the HIP "
+                           "runtime crashed inside a backward graph launch in two of four processes (DESIGN.md 4.7)")
     import torch.distributed as dist
     multi_rank = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     for name, m in decoder.named_modules():

@@ -574,6 +574,23 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
                                            compute_locations(H, W, stride=mask_feat_stride, device=mask_feats.device))
             scale, loc = tab                                                         # [2], [HW, 2]
             inst = ref_xy * scale                                                    # [N, Q, 2]
+            if (params.dtype == torch.float32 and feats.dtype == torch.float32 and ref_xy.dtype == torch.float32
+                    and not torch.is_autocast_enabled()):
+                # full-precision training path.  The two coordinate terms ride in the GEMM:
+                #   x0 = [W_f | -w_x | -w_y] . [F; lx; ly]  +  (b0 + w_x rx + w_y ry)
+                # -- one batched GEMM with the bias as its addend instead of a GEMM, the [N, Q, HW, 2] difference tensor, two
+                # fused multiply-adds and a bias pass over [N, Q, 8, HW] (each of them a kernel forward and two backward on
+                # 315 MB at 2 x 300 queries, 128^2 pixels).  Same sum in another order: the products w_x rx and w_x lx are
+                # rounded separately (|error| <= 2^-24 * 2 * |w_x| * image size per term: 6e-5 |w_x| at 512 px).
+                # (16-bit autocast keeps the form below: a pixel coordinate does not survive a bf16 GEMM operand; so does fp64,
+                # where the reference's `.float()` of the relative coordinates is a rounding of its own)
+                fe = torch.cat((feats, loc.to(feats.dtype).t().unsqueeze(0).expand(N, 2, H * W)), dim=1)     # [N, C + 2, HW]
+                wx = torch.cat((w0[..., 2:], -w0[..., 0:2]), dim=-1).reshape(N, Q * ch, C + 2)
+                bias0 = b0 + (w0[..., 0:2] * inst[:, :, None, :].to(w0.dtype)).sum(-1)                        # [N, Q, ch]
+                x = torch.baddbmm(bias0.reshape(N, Q * ch, 1), wx, fe).relu_().view(N * Q, ch, H * W)
+                x = torch.baddbmm(b1.reshape(N * Q, ch, 1), w1.reshape(N * Q, ch, ch), x).relu_()
+                x = torch.baddbmm(b2.reshape(N * Q, 1, 1), w2.reshape(N * Q, 1, ch), x)
+                return x.reshape(N, Q, H, W)
             rel = (inst[:, :, None, :] - loc[None, None, :, :]).float()              # [N, Q, HW, 2]
             x = torch.bmm(w0[..., 2:].reshape(N, Q * ch, C), feats).view(N, Q, ch, H * W)
             x = torch.addcmul(x, w0[..., 0:1], rel[:, :, None, :, 0])

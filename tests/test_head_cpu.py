@@ -173,6 +173,38 @@ def test_dynamic_mask_head_batched_equals_reference_formulation(rel_coord):
     np.testing.assert_array_equal(attn_mask[:, 0].numpy(), (a.sigmoid().flatten(2) < 0.5).numpy())
 
 
+def test_dynamic_mask_head_fp32_gemm_form_equals_the_reference_formulation():
+    """fp32 (the training path outside autocast): coordinate terms and biases folded into the three batched GEMMs -- values
+    and the gradients of features, reference points and generated parameters against the reference formulation evaluated in
+    fp64 on the same fp32 inputs, at a 512-pixel image size (where the separately rounded w * r and w * l products matter most),
+    with bounds scaled by the pre-activation magnitudes."""
+    d = _small_decoder()
+    N, Q, H, W = 2, 6, 128, 128
+    torch.manual_seed(3)
+    mf = torch.randn(N, 16, H, W, requires_grad=True)
+    ref = torch.rand(Q, N, 2, requires_grad=True)
+    prm = (torch.randn(Q, N, d.num_gen_params) * 0.3).requires_grad_(True)
+    got = d.mask_heads_forward_batched(mf, ref.transpose(0, 1), prm.transpose(0, 1), 4, True)
+    go = torch.randn_like(got)
+    g_got = torch.autograd.grad(got, (mf, ref, prm), go)
+    d64 = _small_decoder().double()
+    mf64, ref64, prm64 = (t.detach().double().requires_grad_(True) for t in (mf, ref, prm))
+    want = _reference_formulation(d64, mf64, ref64, prm64)
+    g_want = torch.autograd.grad(want, (mf64, ref64, prm64), go.double())
+    # pre-activations reach |w| * 512 px * 8 inputs: fp32 rounding of such sums, three layers deep
+    scale = float(want.detach().abs().max())
+    assert float((got.detach().double() - want.detach()).abs().max()) <= 2e-5 * scale
+    # gradients: a pre-activation within rounding of zero may take the other side of its ReLU in fp32 (a finite change of a few
+    # elements, in ANY fp32 evaluation): all-element bound on the norm, element-wise bound on all but 1e-4 of the elements
+    for a, b in zip(g_got, g_want):
+        err = (a.double() - b).abs()
+        assert float(err.norm()) <= 1e-3 * float(b.norm())
+        if b.numel() >= 10000:
+            assert float((err > 2e-4 * float(b.abs().max())).double().mean()) <= 1e-4
+        else:                                    # (reference points: 24 sums over 16 384 pixels x 8 channels each, in fp32)
+            assert float(err.max()) <= 2e-3 * float(b.abs().max())
+
+
 def test_zero_rel_coord_weights_reduce_to_plain_conv_stack():
     """Invariant from SURVEY.md 8c: with the two relative-coordinate weights zeroed the head is a plain 3-layer MLP."""
     d = _small_decoder().double()

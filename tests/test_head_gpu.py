@@ -364,7 +364,7 @@ def test_graphed_training_front_gives_the_eager_step(tmp_path):
 
 def test_graphed_training_decoder_gives_the_eager_step():
     """graph.graph_training_decoder: the transformer decoder's static-shape core (layers, reference points, ten mask heads,
-    semantic head) forward AND backward replayed from HIP graphs, alone and together with the graphed front; matching,
+    semantic head) forward AND backward replayed from HIP graphs (not combinable with the graphed front); matching,
     contrast items and the criterion eager.  Same losses and gradients as the eager step on the same inputs over three
     replays, every parameter that has a gradient in the eager step has one in the replayed step, BatchNorm statistics not
     moved by the capture, eval path untouched, another crop size refused."""
@@ -378,7 +378,7 @@ def test_graphed_training_decoder_gives_the_eager_step():
     torch.manual_seed(0)
     cfg = get_cfg(num_queries=12, norm="BN", sem_norm="BN", enc_layers=2, dec_layers=4, train_num_points=512, dataset="BBBC")
     eager = mfm.MaskFormer(**mfm.MaskFormer.from_config(cfg, ResNet(18, 3, norm="BN"))).cuda().train()
-    dec_only, both = copy.deepcopy(eager), copy.deepcopy(eager)
+    dec_only = copy.deepcopy(eager)
     H = W = 128
     vol = torch.randn(2, 3, H, W, device="cuda")
     targets = []
@@ -389,10 +389,10 @@ def test_graphed_training_decoder_gives_the_eager_step():
                         "fg_masks": (masks.sum(0) > 0).float(), "center_points": centers})
     stats = {n: b.clone() for n, b in dec_only.named_buffers()}
     graph.graph_training_decoder(dec_only, vol)
-    graph.graph_training_decoder(both, vol)
-    graph.graph_training_front(both, vol)
     assert graph.has_graphed_decoder(dec_only) and parallel.has_graphed_front(dec_only)
-    for model in (dec_only, both):
+    with pytest.raises(RuntimeError, match="one capture or the other"):
+        graph.graph_training_front(dec_only, vol)
+    for model in (dec_only,):
         assert sorted(model.state_dict()) == sorted(eager.state_dict())
         for n, b in model.named_buffers():
             assert torch.equal(b, stats[n]), n                                    # capture passes did not move the statistics
@@ -408,7 +408,7 @@ def test_graphed_training_decoder_gives_the_eager_step():
                 {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
 
     le, ge = step(eager)
-    for model in (dec_only, both):
+    for model in (dec_only,):
         for _ in range(3):
             lg, gg = step(model)
             assert lg.keys() == le.keys()
@@ -435,9 +435,8 @@ def test_graphed_training_decoder_gives_the_eager_step():
         a, _ = dec_only(vol)
         b, _ = eager(vol)
     assert torch.equal(a, b)                                                      # the eval path is the eager one
-    for model in (dec_only, both):
-        graph.release_training_graphs(model)
-        assert not parallel.has_graphed_front(model) and not graph.has_graphed_decoder(model)
+    graph.release_training_graphs(dec_only)
+    assert not parallel.has_graphed_front(dec_only) and not graph.has_graphed_decoder(dec_only)
     copy.deepcopy(dec_only)                                                       # an ordinary module again
 
 

@@ -77,8 +77,6 @@ def main():
         configs.update({k + " + graphed backbone / pixel decoder": dict(v, graph_front=True) for k, v in CONFIGS.items()})
     if "--graph-decoder" in sys.argv:
         configs.update({k + " + graphed decoder core": dict(v, graph_decoder=True) for k, v in CONFIGS.items()})
-        configs.update({k + " + graphed decoder core + backbone / pixel decoder": dict(v, graph_decoder=True, graph_front=True)
-                        for k, v in CONFIGS.items()})
     for name, c in configs.items():
         model, step = build(c)
         for _ in range(3):
