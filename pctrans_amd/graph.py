@@ -184,19 +184,22 @@ def has_graphed_decoder(model):
 
 def graph_training_decoder(model, example_volume, warmup=3):
     """Capture the transformer decoder's STATIC-SHAPE core -- input projections, the nine cross-attention / self-attention /
-    FFN layers, reference-point updates, the ten dynamic mask heads and the semantic head, forward AND backward -- as HIP
-    graphs (torch.cuda.make_graphed_callables), in place.  This is the host-bound part of a training step at the
-    reference's per-GPU batch of two crops (thousands of launches on [Q, N, C]-sized tensors); what follows the matching --
-    the ten Hungarian assignments, the query-contrast items and the criterion -- stays eager (its shapes follow the
-    targets).  `MultiScaleMaskedTransformerDecoder.forward` evaluates the core first and the matching afterwards in the
-    eager path too, so eager and replayed steps run the same operations in the same order.
+    FFN layers, reference-point updates and the ten dynamic mask heads, forward AND backward -- as HIP graphs
+    (torch.cuda.make_graphed_callables), in place.  This is the host-bound part of a training step at the reference's
+    per-GPU batch of two crops (thousands of launches on [Q, N, C]-sized tensors); what follows the matching -- the ten
+    Hungarian assignments, the query-contrast items and the criterion -- and the semantic head stay eager.
+    `MultiScaleMaskedTransformerDecoder.forward` evaluates the core first and the matching afterwards in the eager path too,
+    so eager and replayed steps run the same operations in the same order.
 
-    Same restrictions as graph_training_front (single-rank or frozen-norm: the semantic head's BatchNorm is inside the
-    core; outside torch.autocast; fixed crop size and batch; no deep copy / pickle of the captured model), decoder dropout
-    must be 0 (the shipped configurations: a captured dropout mask would repeat).  NOT combinable with graph_training_front
-    (either raises when the other is in place): measured, the decoder core alone is the faster capture (configs[2]: 74.9 ms
-    against 80.1 for the front and 77.3 for both), and with both in place a backward graph launch crashed the HIP runtime in
-    two of four processes of tools/record_train_configs.py.  Returns the model."""
+    The core holds no BatchNorm (the decoder's only one, SyncBN in the shipped yamls, sits in the semantic head, which is
+    outside), no dropout (checked: a captured mask would repeat) and no collective: it can be captured on a model whose norms
+    are already SyncBatchNorm and on every rank of a DistributedDataParallel job -- call it after parallel.convert_norms and
+    BEFORE wrapping the model in DDP (then make_parallel(..., norm_mode=None)); the gradients leave the graph as ordinary
+    autograd outputs, so DDP's bucket hooks fire as in the eager step (tools/rehearse_ddp_sync_bn.py --graph-decoder, two
+    ranks: gradients bitwise equal across ranks).  Outside torch.autocast; fixed crop size and batch; no deep copy / pickle of
+    the captured model.  NOT combinable with graph_training_front (either raises when the other is in place): measured, the
+    decoder core alone is the faster capture (configs[2]: 72.2 ms against 81.2 for the front), and with both in place a
+    backward graph launch crashed the HIP runtime in two of four processes of tools/record_train_configs.py.  Returns the model."""
     head = model.sem_seg_head
     decoder = head.predictor
     if "_pct_graphed_core" in decoder.__dict__:
@@ -205,16 +208,12 @@ def graph_training_decoder(model, example_volume, warmup=3):
         raise RuntimeError("graph_training_decoder: this model's front is captured (graph_training_front) -- use one capture or "
                            "the other: the decoder core alone is the faster of the two, and with both captured the HIP "
                            "runtime crashed inside a backward graph launch in two of four processes (DESIGN.md 4.7)")
-    import torch.distributed as dist
-    multi_rank = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     for name, m in decoder.named_modules():
-        if isinstance(m, torch.nn.SyncBatchNorm):
-            raise RuntimeError("graph_training_decoder: predictor.%s is a SyncBatchNorm -- its cross-rank all_gather cannot be "
-                               "captured into a HIP graph; capture on a single-rank / frozen-norm model only" % name)
-        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and multi_rank:
-            raise RuntimeError("graph_training_decoder: predictor.%s is a BatchNorm and %d ranks are running -- the captured "
-                               "graphs would keep per-rank statistics where the reference synchronises them (build.py:80-81)"
-                               % (name, dist.get_world_size()))
+        if name == "logits" or name == "seg_head" or name.startswith("seg_head."):
+            continue                                      # the semantic head runs outside the core
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            raise RuntimeError("graph_training_decoder: predictor.%s is a BatchNorm inside the decoder core -- its statistics "
+                               "(and, as SyncBatchNorm, its all_gather) cannot be part of a captured graph" % name)
         if isinstance(m, torch.nn.Dropout) and m.p > 0:
             raise RuntimeError("graph_training_decoder: predictor.%s has dropout %g -- a captured mask would repeat" % (name, m.p))
         if isinstance(getattr(m, "dropout", None), float) and m.dropout > 0:
@@ -222,20 +221,17 @@ def graph_training_decoder(model, example_volume, warmup=3):
     if torch.is_autocast_enabled():
         raise RuntimeError("graph_training_decoder: call outside torch.autocast (see graph_training_front)")
     was_training = model.training
-    model.train()
-    owned = list(model.named_buffers())                   # (the example pass below runs backbone + pixel decoder in training mode too)
-    buffers = {n: b.detach().clone() for n, b in owned}
-    # example inputs of the core: one eager pass through backbone + pixel decoder (graphed or not: only shapes are used)
+    # example inputs of the core (only their shapes are used): one pass through backbone + pixel decoder in EVAL mode -- no
+    # BatchNorm statistics move and no SyncBatchNorm exchange runs
+    model.eval()
     with torch.no_grad():
         feats = model.backbone(example_volume)
         mask_features, _enc, multi = head.pixel_decoder.forward_features(feats)
+    model.train()
     sample = tuple(t.detach().clone().requires_grad_(True) for t in (mask_features,) + tuple(multi))
     shapes = tuple((tuple(t.shape), t.dtype) for t in sample)
     g_core = torch.cuda.make_graphed_callables(_DecoderCore(decoder), sample, num_warmup_iters=warmup,
                                                allow_unused_input=True)
-    with torch.no_grad():                                 # the example / warm-up / capture passes ran BatchNorms in training mode
-        for n, b in owned:
-            b.copy_(buffers[n])
 
     def core(mask_features, *multi_scale_features):
         if torch.is_autocast_enabled():

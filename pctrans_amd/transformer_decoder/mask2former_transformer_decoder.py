@@ -413,7 +413,9 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         n_pred = self.num_layers + 1
         output, outputs_coords = flat[0], flat[1]
         predictions_mask = list(flat[2:2 + n_pred])
-        sem_logits_pred = flat[2 + n_pred] if self.sem_loss_on else None
+        # the semantic head (:533-534) stays outside the core: it holds the decoder's only BatchNorm (SyncBN in the shipped
+        # yamls), whose cross-rank exchange cannot be part of a captured graph
+        sem_logits_pred = self.logits(self.seg_head(_lp(mask_features))) if self.sem_loss_on else None
 
         indices_list = []
         if targets is not None:
@@ -442,7 +444,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
     def _forward_core(self, mask_features, *x):
         """Everything of `forward` whose shapes do not depend on the targets.  Tensors in, a flat tuple of tensors out (what
         torch.cuda.make_graphed_callables captures): (query features [Q, N, C], stacked reference points [layers, N, Q, 2],
-        the num_layers + 1 mask predictions, [semantic logits])."""
+        the num_layers + 1 mask predictions).  No BatchNorm, no dropout, no random numbers inside."""
         src, pos, size_list = [], [], []
         for i in range(self.num_feature_levels):
             size_list.append(x[i].shape[-2:])
@@ -460,9 +462,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         reference_points = self.ref_point_head(query_embed).sigmoid()
         ref_points = [reference_points]
 
-        mf_lp = _lp(mask_features)                 # one autocast cast shared by the semantic head and the mask head
-        if self.sem_loss_on:
-            sem_logits_pred = self.logits(self.seg_head(mf_lp))
+        mf_lp = _lp(mask_features)
         feats_f32 = None
         if fused_ops.conv1x1_from_token_rows_supported(mask_features, self.mask_head):
             # small batches: the 16-channel projection on the deterministic K = 128 kernel, straight from the encoder's
@@ -514,10 +514,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             predictions_mask.append(outputs_mask)
             outputs_coords.append(outputs_coord)
 
-        flat = (output, torch.stack(outputs_coords)) + tuple(predictions_mask)
-        if self.sem_loss_on:
-            flat = flat + (sem_logits_pred,)
-        return flat
+        return (output, torch.stack(outputs_coords)) + tuple(predictions_mask)
 
     # ------------------------------------------------------------------------------------------------------
     def dynamic_mask_with_coords(self, mask_feats, reference_points, mask_head_params, mask_feat_stride, rel_coord,

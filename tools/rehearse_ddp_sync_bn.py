@@ -33,15 +33,23 @@ def rank_main(args):
     cfg = get_cfg(num_queries=12, norm="BN", sem_norm="BN", enc_layers=2, dec_layers=3, train_num_points=512, dataset="BBBC")
     model = mfm.MaskFormer(**mfm.MaskFormer.from_config(cfg, ResNet(18, 3, norm="BN")))      # same seed on every rank
     n_bn = sum(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules())
-    ddp = parallel.make_parallel(model, device, parallel="DDP", norm_mode="sync_bn")
+    H = W = 128
+    g = torch.Generator(device="cuda").manual_seed(100 + rank)                                # a different shard per rank
+    vol = torch.randn(2, 3, H, W, device="cuda", generator=g)
+    if args.graph_decoder:
+        # the decoder's static-shape core from HIP graphs on every rank: norms converted first, capture, then DDP
+        from pctrans_amd import graph
+        model = parallel.convert_norms(model).to(device)
+        graph.graph_training_decoder(model, vol)
+        ddp = parallel.make_parallel(model, device, parallel="DDP", norm_mode=None)
+        assert graph.has_graphed_decoder(ddp.module)
+    else:
+        ddp = parallel.make_parallel(model, device, parallel="DDP", norm_mode="sync_bn")
     net = ddp.module
     n_sync = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in net.modules())
     assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel) and ddp.find_unused_parameters
     assert n_bn >= 10 and n_sync == n_bn, (n_bn, n_sync)
     opt = torch.optim.SGD(ddp.parameters(), lr=1e-3, momentum=0.9)
-    H = W = 128
-    g = torch.Generator(device="cuda").manual_seed(100 + rank)                                # a different shard per rank
-    vol = torch.randn(2, 3, H, W, device="cuda", generator=g)
     yy, xx = torch.meshgrid(torch.arange(H, device="cuda"), torch.arange(W, device="cuda"), indexing="ij")
 
     def blob(cy, cx, r):
@@ -80,6 +88,8 @@ def main():
     ap.add_argument("--ranks", type=int, default=2)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--out", default=None, help="directory for the per-rank dumps (default: a temporary directory)")
+    ap.add_argument("--graph-decoder", action="store_true",
+                    help="capture the decoder core in HIP graphs on every rank (graph.graph_training_decoder) before DDP")
     args = ap.parse_args()
     if "RANK" in os.environ:
         return rank_main(args)
@@ -95,7 +105,8 @@ def main():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
     rc = subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.ranks),
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
-                          "--ranks", str(args.ranks), "--steps", str(args.steps), "--out", args.out], env=env)
+                          "--ranks", str(args.ranks), "--steps", str(args.steps), "--out", args.out]
+                         + (["--graph-decoder"] if args.graph_decoder else []), env=env)
     if rc != 0:
         sys.exit(rc)
     import torch
@@ -106,7 +117,7 @@ def main():
             worst = max(worst, float((r[0]["grads"][k] - o["grads"][k]).abs().max()))
     same_stats = all(torch.equal(r[0]["stats"][k], o["stats"][k]) for k in r[0]["stats"] for o in r[1:])
     same_params = all(torch.equal(r[0]["params"][k], o["params"][k]) for k in r[0]["params"] for o in r[1:])
-    summary = {"ranks": args.ranks, "backend": "gloo (ranks share cuda:0)", "sync_batchnorm_modules": r[0]["n_sync_bn"],
+    summary = {"ranks": args.ranks, "graphed_decoder": bool(args.graph_decoder), "backend": "gloo (ranks share cuda:0)", "sync_batchnorm_modules": r[0]["n_sync_bn"],
                "gradient_tensors": len(r[0]["grads"]), "max_gradient_difference_between_ranks": worst,
                "running_stats_identical": same_stats, "parameters_identical_after_step": same_params,
                "losses": [x["loss"] for x in r], "targets_per_rank": [x["n_targets"] for x in r],
