@@ -388,8 +388,8 @@ def main():
     # step_ms list below): in three of five first runs on a fresh box two steps about one second into the back-to-back load
     # took 325 ms instead of 106 (a one-off stall of ~440 ms, the same kernels, gone in the next process on that box) while
     # single steps bracketed by synchronisations had already settled at 106 ms -- so the settling is judged on BLOCKS of 5
-    # back-to-back steps, the way the timed region runs: at least 4 blocks, until two consecutive blocks agree within 1.5 %,
-    # at most 8 (40 untimed steps, ~4 s).  With several ranks the count is FIXED (4 blocks): a data-dependent exit would let
+    # back-to-back steps, the way the timed region runs: at least 8 blocks, until two consecutive blocks agree within 1.5 %,
+    # at most 12 (60 untimed steps, ~5.5 s).  With several ranks the count is FIXED (8 blocks): a data-dependent exit would let
     # ranks enter the timed region after different numbers of steps.  Blocks taken and their per-step times go into the JSON
     # line (settle_steps / settle_ms); no collective inside.
     # (Python's cyclic garbage collector stays off from here to the end of the timed region: a generation-2 pass over the module
@@ -399,10 +399,17 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    # (End of round 4: twice in ~15 runs ONE step of 380-450 ms appeared among steps of 90, both times as the second step of
+    # the timed region -- 2.0-2.3 s into the sustained load with 4 settle blocks, and 1-2 steps after the per-launch timing
+    # events start being recorded; its hook-timed kernels took their usual time, the hole was between kernels.  Cause not
+    # established (tools/diag_events.py does not reproduce it).  Both candidates are now put in front of the timed region: the
+    # settle blocks run exactly as the timed steps do -- per-launch events recorded -- and there are at least 8 of them (40
+    # steps, ~3.6 s; at most 12; fixed 8 with several ranks).)
     SETTLE_BLOCK = 5
     prev = None
     settle_ms = []
-    for i_blk in range(8 if world == 1 else 4):
+    MSDA.kernel_timing(True)
+    for i_blk in range(12 if world == 1 else 8):
         torch.cuda.synchronize(device)
         t_s = time.perf_counter()
         for _ in range(SETTLE_BLOCK):
@@ -410,11 +417,12 @@ def main():
         torch.cuda.synchronize(device)
         dt = (time.perf_counter() - t_s) / SETTLE_BLOCK
         settle_ms.append(1e3 * dt)
-        if world == 1 and i_blk >= 3 and prev is not None and abs(dt - prev) <= 0.015 * prev:
+        if world == 1 and i_blk >= 7 and prev is not None and abs(dt - prev) <= 0.015 * prev:
             break
         prev = dt
     for _ in range(args.warmup):
         step()
+    MSDA.kernel_timing(False)          # (the settle's records are dropped)
 
     def fence():
         torch.cuda.synchronize(device)
