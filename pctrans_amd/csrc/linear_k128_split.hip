@@ -33,6 +33,9 @@
 #ifndef PCT_LIN_INTERLEAVE
 #define PCT_LIN_INTERLEAVE 1        /* 16 x 16 form: the next tile's split / LDS stores between the MFMAs (linear1 4.17 -> 3.95 ms, same-box A/B) */
 #endif
+// output rows carry the non-temporal hint (aux bit 1 of the buffer store): written once, read by the NEXT kernel, far larger
+// than the L2 -- merged projections 1.127 -> 1.102 ms at 1.39 M rows, three same-box alternations
+constexpr int SPL_STORE_NT = 2;
 #ifndef PCT_LIN_IL_DELAY
 #define PCT_LIN_IL_DELAY 1          /* merged projections 1.117 -> 1.102 ms (same-box A/B) */
 #endif
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(SPL_BLOCK, 2) void linear_k128_split_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const spl_f32x4 o = *reinterpret_cast<const spl_f32x4 *>(sw + ((lane >> 3) + 8 * i) * SPL_OLD + 4 * (lane & 7));
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(spl_i32x4, o), ry, y_voff, i * y_step, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(spl_i32x4, o), ry, y_voff, i * y_step, SPL_STORE_NT);
         }
       }
     } else {
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(SPL_BLOCK, 2) void linear_k128_split_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const spl_f32x4 o = *reinterpret_cast<const spl_f32x4 *>(sw + ((lane >> 3) + 8 * i) * SPL_OLD + 4 * (lane & 7));
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(spl_i32x4, o), ry, y_voff, i * y_step, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(spl_i32x4, o), ry, y_voff, i * y_step, SPL_STORE_NT);
       }
     }
     }
