@@ -406,16 +406,17 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         assert len(x) == self.num_feature_levels
         del mask          # padding masks are not applied on this path (:509-510)
         graphed = self.__dict__.get("_pct_graphed_core")
+        mf_lp = _lp(mask_features)                 # one autocast cast shared by the semantic head and the mask head
         if graphed is not None and self.training and torch.is_grad_enabled():
             flat = graphed(mask_features, *x)
         else:
-            flat = self._forward_core(mask_features, *x)
+            flat = self._forward_core(mask_features, *x, _mf_lp=mf_lp)
         n_pred = self.num_layers + 1
         output, outputs_coords = flat[0], flat[1]
         predictions_mask = list(flat[2:2 + n_pred])
         # the semantic head (:533-534) stays outside the core: it holds the decoder's only BatchNorm (SyncBN in the shipped
         # yamls), whose cross-rank exchange cannot be part of a captured graph
-        sem_logits_pred = self.logits(self.seg_head(_lp(mask_features))) if self.sem_loss_on else None
+        sem_logits_pred = self.logits(self.seg_head(mf_lp)) if self.sem_loss_on else None
 
         indices_list = []
         if targets is not None:
@@ -441,7 +442,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             out["sem_mask"] = sem_logits_pred
         return out
 
-    def _forward_core(self, mask_features, *x):
+    def _forward_core(self, mask_features, *x, _mf_lp=None):
         """Everything of `forward` whose shapes do not depend on the targets.  Tensors in, a flat tuple of tensors out (what
         torch.cuda.make_graphed_callables captures): (query features [Q, N, C], stacked reference points [layers, N, Q, 2],
         the num_layers + 1 mask predictions).  No BatchNorm, no dropout, no random numbers inside."""
@@ -462,7 +463,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         reference_points = self.ref_point_head(query_embed).sigmoid()
         ref_points = [reference_points]
 
-        mf_lp = _lp(mask_features)
+        mf_lp = _mf_lp if _mf_lp is not None else _lp(mask_features)     # (the eager caller hands its cast over)
         feats_f32 = None
         if fused_ops.conv1x1_from_token_rows_supported(mask_features, self.mask_head):
             # small batches: the 16-channel projection on the deterministic K = 128 kernel, straight from the encoder's
