@@ -408,21 +408,30 @@ def main():
     SETTLE_BLOCK = 5
     prev = None
     settle_ms = []
-    MSDA.kernel_timing(True)
-    for i_blk in range(12 if world == 1 else 8):
+    # (PCT_BENCH_SETTLE_BLOCKS: fewer blocks for counter-collection runs -- `rocprofv3 --pmc` around this script ends in a
+    # segmentation fault inside the profiler once a run passes ~30 000 dispatches with four counters, tools/pmc_bench_*.sh set 2;
+    # the count taken is in the JSON line)
+    settle_min = max(1, int(os.environ.get("PCT_BENCH_SETTLE_BLOCKS", "8")))
+    for i_blk in range(settle_min + 4 if world == 1 else settle_min):
+        MSDA.kernel_timing(True)
         torch.cuda.synchronize(device)
         t_s = time.perf_counter()
         for _ in range(SETTLE_BLOCK):
             step()
         torch.cuda.synchronize(device)
         dt = (time.perf_counter() - t_s) / SETTLE_BLOCK
+        # (the block's records are dropped, its events reused by the next block: the number of live timing events stays that
+        # of one block)
+        MSDA.kernel_timing(False, recycle=True)
         settle_ms.append(1e3 * dt)
-        if world == 1 and i_blk >= 7 and prev is not None and abs(dt - prev) <= 0.015 * prev:
+        if world == 1 and i_blk >= settle_min - 1 and prev is not None and abs(dt - prev) <= 0.015 * prev:
             break
         prev = dt
+    MSDA.kernel_timing(True)
     for _ in range(args.warmup):
         step()
-    MSDA.kernel_timing(False)          # (the settle's records are dropped)
+    torch.cuda.synchronize(device)
+    MSDA.kernel_timing(False, recycle=True)
 
     def fence():
         torch.cuda.synchronize(device)

@@ -6,9 +6,12 @@ _TIMING = None
 _POOL = []            # events created AND recorded once before a timed region (reserve): taken before new ones are made
 
 
-def kernel_timing(enable):
+def kernel_timing(enable, recycle=False):
     """kernel_timing(True) starts collecting; kernel_timing(False) stops and returns [(name, milliseconds), ...]
-    ((name, milliseconds, info) for launches that carry one: the MSDeformAttn forward reports the kernel id it ran)."""
+    ((name, milliseconds, info) for launches that carry one: the MSDeformAttn forward reports the kernel id it ran).
+    `recycle` (with False): the events just read go back to the pool `timed` draws from, so a caller that times block after
+    block keeps a bounded number of live events (bench.py's settle blocks: thousands of live timing events made
+    `rocprofv3 --pmc` crash around the script)."""
     global _TIMING
     if enable:
         _TIMING = []
@@ -18,6 +21,9 @@ def kernel_timing(enable):
     for name, e0, e1, info in rec:
         e1.synchronize()
         out.append((name, e0.elapsed_time(e1)) if info is None else (name, e0.elapsed_time(e1), info))
+        if recycle:
+            _POOL.append(e0)
+            _POOL.append(e1)
     return out
 
 

@@ -2,6 +2,7 @@
 # Issue-side counters of the step's hand-written kernels inside bench.py (GPU box, repo root): which unit each one keeps busy.
 #   tools/pmc_bench_issue.sh   ->  gpurun_out/r04_bench_issue.txt  (copy to profiles/)
 cd /tmp && export TMPDIR=/tmp
+export PCT_BENCH_SETTLE_BLOCKS=2    # the profiler does not survive a full-length settle with counters on (bench.py)
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/pmc_issue
 i=0

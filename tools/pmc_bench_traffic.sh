@@ -3,6 +3,7 @@
 # --pmc passes (run on the GPU box from the repo root):   tools/pmc_bench_traffic.sh [M|I]
 # writes gpurun_out/r04_msda_traffic_batch<B>_dist<D>.json for bench.py's default batch; copy it to profiles/.
 cd /tmp && export TMPDIR=/tmp
+export PCT_BENCH_SETTLE_BLOCKS=2    # the profiler does not survive a full-length settle with counters on (bench.py)
 R=$GRAFT_REPO_ROOT
 D=${1:-M}
 rm -rf $R/gpurun_out/pmc_traffic_$D
